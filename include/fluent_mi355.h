@@ -1,0 +1,97 @@
+/* fluent_mi355.h — C-ABI of libfluent_mi355.so (MI355X / gfx950 native hot path for
+ * SGLang-FluentLLM: FP8 MLA decode + FP8 block-scaled grouped GEMM).
+ *
+ * Every entry point below is what the reference's Python operator API for this path binds to
+ * (citations are /root/reference/python/sglang/... file:line of the call site replaced).
+ * Conventions: plain pointers to DEVICE memory unless the name says host; sizes in elements;
+ * `stream` is a hipStream_t passed as void*; return 0 = ok, non-zero = error (message via
+ * fl_last_error()).  No entry point synchronises the host, allocates device memory, or keeps
+ * global mutable state: everything is hipGraph-capturable (srt/model_executor/cuda_graph_runner.py:433).
+ */
+#ifndef FLUENT_MI355_H
+#define FLUENT_MI355_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fl_stream_t;
+
+#define FL_OK 0
+#define FL_ERR_INVALID 1
+#define FL_ERR_LAUNCH 2
+#define FL_ERR_UNSUPPORTED 3
+
+#define FL_MLA_PAGE 64        /* srt/layers/attention/flashmla_backend.py:25 PAGE_SIZE */
+#define FL_MLA_META_W 8       /* ints per tile-scheduler row */
+#define FL_MLA_ROWS_PER_WG 64 /* query rows (s_q*H) one workgroup owns */
+
+/* KV-cache formats (srt/mem_cache/memory_pool.py:635-658) */
+#define FL_KV_FP8_PER_TOKEN 0 /* (u8[.,512], f32[.,1], bf16[.,64]) tuple, quant_method="per_token_head" */
+#define FL_KV_FP8_576 1       /* one fp8 [.,576] tensor, descale scalars */
+#define FL_KV_BF16_576 2      /* one bf16 [.,576] tensor */
+
+const char* fl_last_error(void);
+int fl_version(void);
+/* number of compute units of HIP device `device` (host query, cached) */
+int fl_device_cu_count(int device, int* cu_count);
+
+/* ---- K3: get_mla_metadata (flashmla_backend.py:261-265,276-280,307-321,335-339,380-384) ----
+ * num_parts rows of FL_MLA_META_W int32 + num_splits[bs+1]; shapes static in bs. */
+int fl_mla_num_parts(int cu_count, int rows_per_kv_head);
+int fl_mla_get_metadata(const int32_t* cache_seqlens, int bs, int num_parts,
+                        int32_t* tile_scheduler_metadata, int32_t* num_splits, fl_stream_t stream);
+
+/* ---- K4: quantize_ckv_per_token_head (flashmla_backend.py:125,206) ----
+ * q bf16 [rows, d_nope+d_rope] -> q_nope fp8 [rows,d_nope], q_scale f32 [rows], q_rope bf16 [rows,d_rope] */
+int fl_mla_quant_q(const void* q, int64_t rows, int d_nope, int d_rope, void* q_nope, float* q_scale,
+                   void* q_rope, fl_stream_t stream);
+
+/* ---- K5: quantize_and_cache_k (srt/mem_cache/memory_pool.py:864-871,902-909; fallback :873-880) ----
+ * key bf16 [n, d_nope+d_rope]; scatter into the three caches at slot indices[i]. */
+int fl_mla_quant_store_k(const void* key, int64_t n, int d_nope, int d_rope, const int32_t* indices,
+                         void* k_lora_cache, float* k_scale_cache, void* k_rope_cache, int64_t num_slots,
+                         fl_stream_t stream);
+
+/* ---- K6: dequantize_ckv_fused_indexed (memory_pool.py:821-824; fallback :826-831) ---- */
+int fl_mla_dequant_gather(const void* k_lora_cache, const void* k_rope_cache, const float* k_scale_cache,
+                          const int32_t* indices, int64_t n, int d_nope, int d_rope, int64_t num_slots,
+                          void* k_lora_out, void* k_rope_out, fl_stream_t stream);
+
+/* ---- K1/K2: flash_mla_ckv_fp8_per_token / flash_mla_with_kvcache
+ * (flashmla_backend.py:208-222,127-142 / :227-254,145-175) ---- */
+typedef struct FlMlaDecodeArgs {
+  int32_t kv_format;        /* FL_KV_* */
+  int32_t bs, s_q, h_q;     /* q rows per request = s_q*h_q (one latent KV head) */
+  int32_t d_nope, d_rope;   /* 512, 64 */
+  int32_t causal;           /* query j sees keys [0, seqlen-(s_q-1-j)) when causal */
+  int32_t num_parts;        /* rows of tile_scheduler_metadata */
+  float softmax_scale;
+  float descale_q, descale_k; /* FL_KV_FP8_576 only */
+  /* query */
+  const void* q_nope;       /* fp8 [bs,s_q,h_q,d_nope] (per-token) | fp8/bf16 [bs,s_q,h_q,576] */
+  const void* q_rope;       /* bf16 [bs,s_q,h_q,d_rope] (per-token only) */
+  const float* q_scale;     /* f32 [bs,s_q,h_q] (per-token only) */
+  /* paged cache */
+  const void* k_nope;       /* u8 [pages,64,d_nope] | [pages,64,576] */
+  const void* k_rope;       /* bf16 [pages,64,d_rope] (per-token only) */
+  const float* k_scale;     /* f32 [pages,64] (per-token only) */
+  int64_t num_pages;
+  const int32_t* block_table; /* i32 [bs, block_table_stride] page ids (bit-exact, allocator.py:60-102) */
+  int64_t block_table_stride;
+  const int32_t* cache_seqlens; /* i32 [bs] */
+  const int32_t* tile_scheduler_metadata; /* from fl_mla_get_metadata */
+  const int32_t* num_splits;
+  /* outputs */
+  void* out;                /* bf16 [bs,s_q,h_q,d_nope] */
+  float* lse;               /* f32 [bs,h_q,s_q] natural-log LSE */
+  float* o_accum;           /* f32 [bs+num_parts, s_q*h_q, d_nope] split-KV workspace (caller-owned) */
+  float* lse_accum;         /* f32 [bs+num_parts, s_q*h_q] */
+} FlMlaDecodeArgs;
+
+int fl_mla_decode(const FlMlaDecodeArgs* args, fl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,92 @@
+"""TEST INFRASTRUCTURE ONLY (container-side): import harness for the real reference.
+
+Makes `/root/reference/python/sglang` importable on CPU in THIS container so that
+`oracle/gen_golden.py` can run the reference's own torch-native code and emit golden
+vectors.  Nothing here travels to the GPU box in a usable form: /root/reference does
+not exist there, and no test, smoke() or bench reads it at run time.
+
+Recipe follows SURVEY.md §8(c): stub absent third-party packages with MagicMock,
+force the non-HIP branches (`torch.version.hip = None`), never write bytecode into
+the read-only reference tree.
+"""
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+REF_ROOT = "/root/reference/python"
+
+_STUB_TOPLEVEL = {
+    "pybase64", "zmq", "eps", "flashinfer", "flash_mla_fp8", "flash_mla_swap", "flash_mla",
+    "deep_gemm", "deep_gemm_oss", "compressed_tensors", "openai", "vllm", "orjson", "uvloop",
+    "sgl_kernel", "outlines", "xgrammar", "llguidance", "interegular", "partial_json_parser",
+    "setproctitle", "torchao", "decord", "cuda", "pynvml", "modelscope", "torch_memory_saver",
+    "mooncake", "nixl", "deep_ep", "fast_hadamard_transform", "tilelang", "blobfile", "tiktoken",
+    "IPython", "gguf", "einx", "msgspec", "soundfile", "scipy_stub", "triton_kernels",
+}
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split(".")[0] in _STUB_TOPLEVEL:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = MagicMock(name=spec.name)
+        m.__name__ = spec.name
+        m.__path__ = []
+        m.__spec__ = spec
+        m.__loader__ = self
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def install():
+    """Idempotently prepare sys.path / stubs. Returns True when the reference is present."""
+    if not os.path.isdir(REF_ROOT):
+        return False
+    sys.dont_write_bytecode = True
+    os.environ.setdefault("PYTHONPYCACHEPREFIX", "/tmp/pyc")
+    sys.pycache_prefix = "/tmp/pyc"
+    import torch
+
+    torch.version.hip = None
+    if not any(isinstance(f, _StubFinder) for f in sys.meta_path):
+        sys.meta_path.append(_StubFinder())
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    return True
+
+
+def load_functions_from_source(path, names, namespace):
+    """exec() selected top-level FunctionDefs of a reference file that does not import as a
+    module (stale imports) into `namespace`. Used only to RUN them here."""
+    import ast
+
+    with open(path) as f:
+        tree = ast.parse(f.read())
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    mod = ast.Module(body=picked, type_ignores=[])
+    exec(compile(mod, path, "exec"), namespace)
+    return namespace
+
+
+def load_method_from_source(path, cls_name, method_name, namespace):
+    """exec() one method of one class of a reference file (whose module does not import under
+    stubs) as a free function in `namespace`; returns it. Used only to RUN it here."""
+    import ast
+
+    with open(path) as f:
+        tree = ast.parse(f.read())
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == cls_name:
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name == method_name:
+                    exec(compile(ast.Module(body=[item], type_ignores=[]), path, "exec"), namespace)
+                    return namespace[method_name]
+    raise KeyError(f"{cls_name}.{method_name} not found in {path}")

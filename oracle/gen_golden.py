@@ -1,0 +1,205 @@
+"""TEST INFRASTRUCTURE ONLY (build-container side).  Generates tests/golden/*.npz.
+
+Runs the REAL reference (imported from /root/reference/python via oracle/_ref_import.py) on
+seeded inputs and records inputs + outputs as data fixtures.  The fixtures pin oracle/*.py
+(tests/test_oracle_golden.py) and are compared with the HIP path on the GPU box, where the
+reference itself does not exist.  Re-run:  python -B oracle/gen_golden.py
+
+Reference entry points exercised (file:line under /root/reference/python/sglang):
+  srt/layers/attention/torch_native_backend.py:472-528,275-343   TorchNativeAttnBackend.forward_decode
+  srt/mem_cache/memory_pool.py:854-882,817-839                   MLATokenToKVPool.set_kv_buffer / get_key_split_contiguous
+  srt/mem_cache/allocator.py:60-102                              KVAllocator.alloc
+  test/test_block_fp8.py:15-40,89-141,212-241                    native fp8 quant / block matmul / MoE oracles
+  srt/layers/activation.py:58-60                                 SiluAndMul.forward_native
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_import  # noqa: E402
+
+assert _ref_import.install(), "reference tree not present: golden vectors can only be generated in the build container"
+import torch  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def bf(x):  # bf16 tensor -> uint16 numpy
+    return x.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def f8(x):  # fp8 tensor -> uint8 numpy
+    return x.contiguous().view(torch.uint8).numpy()
+
+
+def gen_mla_torch_native():
+    from sglang.srt.layers.attention.torch_native_backend import TorchNativeAttnBackend
+    from sglang.srt.layers.radix_attention import RadixAttention
+    from sglang.srt.mem_cache.memory_pool import MLATokenToKVPool, ReqToTokenPool
+    from sglang.srt.model_executor.forward_batch_info import ForwardBatch, ForwardMode
+
+    cases = {
+        # BASELINE.json configs[0]: kv_lora=512, 16 heads, bs=1, seq=128
+        "cfg1": dict(H=16, lens=[128], seed=0),
+        # ragged: page-boundary lengths 1/63/64/65/130, scattered pages
+        "ragged": dict(H=16, lens=[1, 63, 64, 65, 130], seed=1),
+        "h128": dict(H=128, lens=[200, 77], seed=2),
+    }
+    for name, c in cases.items():
+        H, lens = c["H"], c["lens"]
+        g = torch.Generator().manual_seed(c["seed"])
+        bs = len(lens)
+        max_ctx = 256
+        npages = sum((L + 63) // 64 for L in lens)
+        size = (npages + 2) * 64
+        pool = MLATokenToKVPool(size, model_dtype=torch.bfloat16, dtype=torch.bfloat16, quant_method="none",
+                                kv_lora_rank=512, qk_rope_head_dim=64, layer_num=1, device="cpu",
+                                enable_memory_saver=False, max_batch_size=bs, max_context_len=max_ctx,
+                                page_size=64, rank=0, enable_alt_stream=False)
+        r2t = ReqToTokenPool(bs, max_ctx, "cpu", False)
+        layer = RadixAttention(H, 576, 192 ** -0.5, num_kv_heads=1, layer_id=0, v_head_dim=512)
+        perm = (torch.randperm(npages, generator=g) + 1).tolist()  # page 0 = padding page
+        block_table = torch.zeros(bs, max_ctx // 64, dtype=torch.int32)
+        kv_all = torch.randn(size + 64, 1, 576, generator=g).to(torch.bfloat16)
+        pool.kv_buffer[0].copy_(kv_all)
+        pi = 0
+        out_loc = []
+        for b, L in enumerate(lens):
+            for t in range(L):
+                if t % 64 == 0:
+                    block_table[b, t // 64] = perm[pi]
+                    pi += 1
+                r2t.req_to_token[b, t] = int(block_table[b, t // 64]) * 64 + t % 64
+            out_loc.append(int(r2t.req_to_token[b, L - 1]))
+        q = torch.randn(bs, H * 576, generator=g).to(torch.bfloat16)
+        k_new = torch.randn(bs, 1, 576, generator=g).to(torch.bfloat16)
+        fb = ForwardBatch(forward_mode=ForwardMode.DECODE, batch_size=bs, input_ids=torch.zeros(bs, dtype=torch.int64),
+                          req_pool_indices=torch.arange(bs), seq_lens=torch.tensor(lens, dtype=torch.int64),
+                          seq_lens_sum=sum(lens), out_cache_loc=torch.tensor(out_loc, dtype=torch.int64),
+                          req_to_token_pool=r2t, token_to_kv_pool=pool)
+        be = TorchNativeAttnBackend(SimpleNamespace(device="cpu"))
+        o = be.forward_decode(q, k_new, k_new[..., :512], layer, fb, save_kv_cache=True)
+        np.savez_compressed(os.path.join(OUT, f"mla_torch_native_{name}.npz"),
+                            H=H, seq_lens=np.array(lens, np.int32), scaling=np.float64(192 ** -0.5),
+                            q=bf(q), k_new=bf(k_new), out_cache_loc=np.array(out_loc, np.int32),
+                            kv_buffer_after=bf(pool.kv_buffer[0]), block_table=block_table.numpy(),
+                            req_to_token=r2t.req_to_token.numpy().astype(np.int32), o=bf(o))
+        print("mla_torch_native", name, tuple(o.shape))
+
+
+def gen_kv_quant():
+    from sglang.srt.layers.radix_attention import RadixAttention
+    from sglang.srt.mem_cache.memory_pool import MLATokenToKVPool
+
+    g = torch.Generator().manual_seed(10)
+    n = 96
+    size = 4 * 64
+    pool = MLATokenToKVPool(size, model_dtype=torch.bfloat16, dtype=torch.float8_e4m3fn,
+                            quant_method="per_token_head", kv_lora_rank=512, qk_rope_head_dim=64, layer_num=1,
+                            device="cpu", enable_memory_saver=False, max_batch_size=4, max_context_len=256,
+                            page_size=64, rank=0, enable_alt_stream=False)
+    for t in pool.kv_buffer[0]:
+        t.view(torch.uint8).zero_() if t.dtype != torch.float32 and t.dtype != torch.bfloat16 else t.zero_()
+    key = torch.randn(n, 1, 576, generator=g)
+    key[0] = 0.0                        # all-zero row -> clamp(1e-26) path
+    key[1] *= 1e-30                     # subnormal-ish amax
+    key[2] *= 1e4                       # large values
+    key[3, 0, :512] = 0.0               # zero latent, non-zero rope
+    key[4] *= 3e-3
+    key[5, 0, 7] = 448.0                # exact fp8 max
+    key[6, 0, :512] = torch.linspace(-1, 1, 512)  # ties
+    key = key.to(torch.bfloat16)
+    loc = (torch.randperm(size, generator=g)[:n] + 64).to(torch.int64)  # skip padding page 0
+    layer = RadixAttention(16, 576, 192 ** -0.5, num_kv_heads=1, layer_id=0, v_head_dim=512)
+    pool.set_kv_buffer(layer, loc, key, key[..., :512])
+    k_lora, k_scale, k_rope = pool.kv_buffer[0]
+    gather = torch.cat([loc[:40], loc[:8]])
+    lora_deq, rope_deq = pool.get_key_split_contiguous(0, gather)
+    np.savez_compressed(os.path.join(OUT, "kv_quant_per_token.npz"), key=bf(key), loc=loc.numpy().astype(np.int32),
+                        k_lora=f8(k_lora), k_scale=k_scale.numpy(), k_rope=bf(k_rope),
+                        gather=gather.numpy().astype(np.int32), lora_deq=bf(lora_deq), rope_deq=bf(rope_deq))
+    print("kv_quant", tuple(k_lora.shape))
+
+
+def gen_alloc():
+    from sglang.srt.mem_cache.allocator import KVAllocator
+
+    al = KVAllocator(size=40 * 64, device="cpu", max_batch_size=4, max_context_len=512, page_size=64)
+    g = torch.Generator().manual_seed(3)
+    al.free_slots = al.free_slots[torch.randperm(len(al.free_slots), generator=g)]  # scattered pages
+    free0 = al.free_slots.clone()
+    steps = [(0, 130, 0), (1, 64, 0), (2, 1, 0), (0, 1, 130), (1, 1, 64), (2, 63, 1), (2, 1, 64), (0, 70, 131), (3, 65, 0)]
+    locs = []
+    for req, need, alloced in steps:
+        locs.append(al.alloc(req, need, alloced).numpy().astype(np.int32))
+    np.savez_compressed(os.path.join(OUT, "kv_alloc.npz"), free_slots=free0.numpy(), steps=np.array(steps, np.int32),
+                        req_to_page=al.req_to_page.numpy(), **{f"loc{i}": l for i, l in enumerate(locs)})
+    print("alloc", al.req_to_page[:, :4].tolist())
+
+
+def gen_gemm():
+    ns = {"torch": torch}
+    ref_test = "/root/reference/python/sglang/test/test_block_fp8.py"
+    # sglang.srt.layers.activation does not import under the stubs (server_args -> openai pydantic models);
+    # run the reference's own SiluAndMul.forward_native body straight from its source file instead.
+    fwd = _ref_import.load_method_from_source("/root/reference/python/sglang/srt/layers/activation.py",
+                                              "SiluAndMul", "forward_native",
+                                              {"torch": torch, "F": torch.nn.functional})
+
+    class SiluAndMul:  # thin holder so that torch_w8a8_block_fp8_moe's `SiluAndMul().forward_native(x)` resolves
+        def forward_native(self, x):
+            return fwd(self, x)
+
+    ns["SiluAndMul"] = SiluAndMul
+    _ref_import.load_functions_from_source(
+        ref_test, {"native_per_token_group_quant_fp8", "native_w8a8_block_fp8_matmul", "torch_w8a8_block_fp8_moe"}, ns)
+    quant, matmul, moe = ns["native_per_token_group_quant_fp8"], ns["native_w8a8_block_fp8_matmul"], ns["torch_w8a8_block_fp8_moe"]
+    g = torch.Generator().manual_seed(20)
+    fp8_max = 448.0
+    # quant
+    x = (torch.randn(83, 512, generator=g) * 3).to(torch.bfloat16)
+    x[0] = 0
+    x[1] *= 1e-12
+    xq, xs = quant(x, 128)
+    # block matmul (recipe of test_block_fp8.py:157-176)
+    M, N, K = 37, 384, 512
+    A = ((torch.rand(M, K, generator=g) - 0.5) * 2 * fp8_max).clamp(-fp8_max, fp8_max).to(torch.float8_e4m3fn)
+    B = ((torch.rand(N, K, generator=g) - 0.5) * 2 * fp8_max).clamp(-fp8_max, fp8_max).to(torch.float8_e4m3fn)
+    As = torch.rand(M, K // 128, generator=g) * 1e-2
+    Bs = torch.rand(N // 128, K // 128, generator=g) * 1e-2
+    C = matmul(A, B, As, Bs, [128, 128], output_dtype=torch.bfloat16)
+    # MoE (recipe of test_block_fp8.py:268-289), E=4, topk=2
+    Bm, D, I, E, topk = 9, 256, 128, 4, 2
+    a = (torch.randn(Bm, D, generator=g) / 10).to(torch.bfloat16)
+    w1 = ((torch.rand(E, 2 * I, D, generator=g) - 0.5) * 2 * fp8_max).clamp(-fp8_max, fp8_max).to(torch.float8_e4m3fn)
+    w2 = ((torch.rand(E, D, I, generator=g) - 0.5) * 2 * fp8_max).clamp(-fp8_max, fp8_max).to(torch.float8_e4m3fn)
+    w1_s = torch.rand(E, 2 * I // 128, D // 128, generator=g) * 1e-2
+    w2_s = torch.rand(E, D // 128, I // 128, generator=g) * 1e-2
+    score = torch.randn(Bm, E, generator=g).to(torch.bfloat16)
+    moe_out = moe(a, w1, w2, w1_s, w2_s, score, topk, [128, 128])
+    sw = torch.softmax(score, dim=-1, dtype=torch.float32)
+    tw, ti = torch.topk(sw, topk)
+    # silu
+    y = (torch.randn(11, 256, generator=g) * 2).to(torch.bfloat16)
+    act = SiluAndMul().forward_native(y)
+    np.savez_compressed(os.path.join(OUT, "gemm_block_fp8.npz"),
+                        quant_x=bf(x), quant_q=f8(xq), quant_s=xs.numpy(),
+                        mm_A=f8(A), mm_B=f8(B), mm_As=As.numpy(), mm_Bs=Bs.numpy(), mm_C=bf(C),
+                        moe_a=bf(a), moe_w1=f8(w1), moe_w2=f8(w2), moe_w1_s=w1_s.numpy(), moe_w2_s=w2_s.numpy(),
+                        moe_topk_w=tw.numpy(), moe_topk_ids=ti.numpy().astype(np.int32), moe_out=bf(moe_out),
+                        silu_x=bf(y), silu_out=bf(act))
+    print("gemm", tuple(C.shape), tuple(moe_out.shape))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    gen_mla_torch_native()
+    gen_kv_quant()
+    gen_alloc()
+    gen_gemm()
+    print("golden written to", OUT)

@@ -1,0 +1,117 @@
+// K4 / K5 / K6 — per-token FP8 quantisation helpers of the MLA latent KV cache.
+//
+//   K5 fl_mla_quant_store_k  == flash_mla_fp8.quantize_and_cache_k   (memory_pool.py:864-871; exact torch
+//                               statement at memory_pool.py:873-880: scale = amax|lora|.clamp(1e-26)/448 in fp32,
+//                               lora/scale -> e4m3fn (RNE), rope/scale -> bf16 (RNE), scatter at `indices`)
+//   K4 fl_mla_quant_q        == flash_mla_fp8.quantize_ckv_per_token_head (flashmla_backend.py:125,206), the same
+//                               arithmetic per (token, head) row of Q
+//   K6 fl_mla_dequant_gather == flash_mla_fp8.dequantize_ckv_fused_indexed (memory_pool.py:821-831)
+//
+// HBM-bound byte work: one 64-lane wave per row, 16-B loads (8 bf16 of the 512-wide latent per lane, one
+// wave-wide shuffle reduction for amax), 8-B fp8 stores.  No LDS.  IEEE fp32 division (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt) so the bytes are bit-identical to the torch statement.
+#include "fl_common.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+
+// row: 576 bf16 = lanes 0..63 hold nope[8*lane .. 8*lane+7] and rope[lane].
+template <bool kScatter>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void quant_rows_kernel(
+    const uint16_t* __restrict__ src, int64_t n, const int32_t* __restrict__ indices, uint8_t* __restrict__ nope_out,
+    float* __restrict__ scale_out, uint16_t* __restrict__ rope_out, int64_t num_slots) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const uint16_t* p = src + row * 576;
+  const uint4 raw = *reinterpret_cast<const uint4*>(p + lane * 8);
+  const float rope = fl_bf16_to_f32(p[512 + lane]);
+  float v[8];
+  v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+  v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+  v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
+  v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));  // NaN inputs are the caller's problem, as in torch
+  amax = fl_wave_max(amax);
+  const float scale = fmaxf(amax, 1e-26f) / FL_FP8_MAX;
+  int64_t dst = row;
+  if (kScatter) {
+    dst = indices[row];
+    if (dst < 0 || dst >= num_slots) return;  // never write out of the pool
+  }
+  uint32_t w0 = fl_cvt_pk_fp8(v[0] / scale, v[1] / scale) | (fl_cvt_pk_fp8(v[2] / scale, v[3] / scale) << 16);
+  uint32_t w1 = fl_cvt_pk_fp8(v[4] / scale, v[5] / scale) | (fl_cvt_pk_fp8(v[6] / scale, v[7] / scale) << 16);
+  *reinterpret_cast<uint2*>(nope_out + dst * 512 + lane * 8) = make_uint2(w0, w1);
+  rope_out[dst * 64 + lane] = fl_f32_to_bf16(rope / scale);
+  if (lane == 0) scale_out[dst] = scale;
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void dequant_gather_kernel(
+    const uint8_t* __restrict__ nope, const uint16_t* __restrict__ rope, const float* __restrict__ scale,
+    const int32_t* __restrict__ indices, int64_t n, int64_t num_slots, uint16_t* __restrict__ nope_out,
+    uint16_t* __restrict__ rope_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n) return;
+  int64_t src = indices[row];
+  if (src < 0 || src >= num_slots) src = 0;  // padding page, like an out-of-range gather would hit page 0
+  const float s = scale[src];
+  const uint2 raw = *reinterpret_cast<const uint2*>(nope + src * 512 + lane * 8);
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t w = i < 2 ? raw.x : raw.y;
+    const uint32_t sh = (i & 1) * 16;
+    const float a = fl_fp8_to_f32((w >> sh) & 0xff) * s;
+    const float b = fl_fp8_to_f32((w >> (sh + 8)) & 0xff) * s;
+    o[i] = (uint32_t)fl_f32_to_bf16(a) | ((uint32_t)fl_f32_to_bf16(b) << 16);
+  }
+  *reinterpret_cast<uint4*>(nope_out + row * 512 + lane * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+  rope_out[row * 64 + lane] = fl_f32_to_bf16(fl_bf16_to_f32(rope[src * 64 + lane]) * s);
+}
+
+}  // namespace
+
+extern "C" int fl_mla_quant_q(const void* q, int64_t rows, int d_nope, int d_rope, void* q_nope, float* q_scale,
+                              void* q_rope, fl_stream_t stream) {
+  FL_CHECK_ARG(d_nope == 512 && d_rope == 64, "fl_mla_quant_q: only d_nope=512,d_rope=64 (got %d,%d)", d_nope, d_rope);
+  FL_CHECK_ARG(rows >= 0 && q && q_nope && q_scale && q_rope, "fl_mla_quant_q: null pointer");
+  if (rows == 0) return FL_OK;
+  const int64_t blocks = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  quant_rows_kernel<false><<<dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream>>>(
+      (const uint16_t*)q, rows, nullptr, (uint8_t*)q_nope, q_scale, (uint16_t*)q_rope, rows);
+  FL_CHECK_LAUNCH("fl_mla_quant_q");
+  return FL_OK;
+}
+
+extern "C" int fl_mla_quant_store_k(const void* key, int64_t n, int d_nope, int d_rope, const int32_t* indices,
+                                    void* k_lora_cache, float* k_scale_cache, void* k_rope_cache, int64_t num_slots,
+                                    fl_stream_t stream) {
+  FL_CHECK_ARG(d_nope == 512 && d_rope == 64, "fl_mla_quant_store_k: only d_nope=512,d_rope=64");
+  FL_CHECK_ARG(n >= 0 && key && indices && k_lora_cache && k_scale_cache && k_rope_cache,
+               "fl_mla_quant_store_k: null pointer");
+  if (n == 0) return FL_OK;
+  const int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+  quant_rows_kernel<true><<<dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream>>>(
+      (const uint16_t*)key, n, indices, (uint8_t*)k_lora_cache, k_scale_cache, (uint16_t*)k_rope_cache, num_slots);
+  FL_CHECK_LAUNCH("fl_mla_quant_store_k");
+  return FL_OK;
+}
+
+extern "C" int fl_mla_dequant_gather(const void* k_lora_cache, const void* k_rope_cache, const float* k_scale_cache,
+                                     const int32_t* indices, int64_t n, int d_nope, int d_rope, int64_t num_slots,
+                                     void* k_lora_out, void* k_rope_out, fl_stream_t stream) {
+  FL_CHECK_ARG(d_nope == 512 && d_rope == 64, "fl_mla_dequant_gather: only d_nope=512,d_rope=64");
+  FL_CHECK_ARG(n >= 0 && k_lora_cache && k_rope_cache && k_scale_cache && indices && k_lora_out && k_rope_out,
+               "fl_mla_dequant_gather: null pointer");
+  if (n == 0) return FL_OK;
+  const int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+  dequant_gather_kernel<<<dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream>>>(
+      (const uint8_t*)k_lora_cache, (const uint16_t*)k_rope_cache, k_scale_cache, indices, n, num_slots,
+      (uint16_t*)k_lora_out, (uint16_t*)k_rope_out);
+  FL_CHECK_LAUNCH("fl_mla_dequant_gather");
+  return FL_OK;
+}

@@ -1,0 +1,199 @@
+"""Host-side mirror of the `flash_mla_fp8` / `flash_mla_swap` Python operator API.
+
+Same names, keyword arguments and return conventions as the calls the reference's
+FlashMLABackend makes (python/sglang/srt/layers/attention/flashmla_backend.py:125-175,206-254,
+261-265; python/sglang/srt/mem_cache/memory_pool.py:821-824,864-871).  Every function marshals
+`tensor.data_ptr()` + the current HIP stream into the C-ABI (include/fluent_mi355.h); outputs are
+allocated with torch.empty on the input device (so the caching allocator / graph pool owns
+them), caches are mutated in place, failures raise RuntimeError.  Nothing here computes.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import FlMlaDecodeArgs, check, cu_count, lib, stream_ptr
+
+PAGE_SIZE = 64
+META_W = 8
+KV_FP8_PER_TOKEN, KV_FP8_576, KV_BF16_576 = 0, 1, 2
+_ONE_BYTE = (torch.uint8, torch.int8, torch.float8_e4m3fn)
+
+
+def _req(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _cuda_contig(t: torch.Tensor, name: str):
+    _req(t.is_cuda, f"{name} must be a device tensor (no CPU fallback on this path)")
+    _req(t.is_contiguous(), f"{name} must be contiguous")
+
+
+def get_mla_metadata(cache_seqlens: torch.Tensor, num_heads_per_head_k: int, num_heads_k: int = 1
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (tile_scheduler_metadata int32 [num_parts, 8], num_splits int32 [bs+1]).
+    Shapes depend only on (device CU count, num_heads_per_head_k) and bs, as the reference's persistent
+    graph buffers require (flashmla_backend.py:307-321,340-341). Runs on-device, no host sync."""
+    _req(num_heads_k == 1, "MLA has one latent KV head (num_heads_k must be 1)")
+    _req(cache_seqlens.dtype == torch.int32, "cache_seqlens must be int32")
+    _cuda_contig(cache_seqlens, "cache_seqlens")
+    bs = cache_seqlens.shape[0]
+    dev = cache_seqlens.device
+    num_parts = lib.fl_mla_num_parts(cu_count(dev), int(num_heads_per_head_k))
+    meta = torch.empty((num_parts, META_W), dtype=torch.int32, device=dev)
+    num_splits = torch.empty((bs + 1,), dtype=torch.int32, device=dev)
+    check(lib.fl_mla_get_metadata(cache_seqlens.data_ptr(), bs, num_parts, meta.data_ptr(), num_splits.data_ptr(),
+                                  stream_ptr(dev)), "fl_mla_get_metadata")
+    return meta, num_splits
+
+
+def quantize_ckv_per_token_head(q: torch.Tensor, kv_lora_rank: int = 512):
+    """q bf16 [bs, s_q, H, 576] -> (q_nope fp8 [..,512], q_scale f32 [..,1], q_rope bf16 [..,64])."""
+    _cuda_contig(q, "q")
+    _req(q.dtype == torch.bfloat16, "q must be bfloat16")
+    d = q.shape[-1]
+    d_rope = d - kv_lora_rank
+    rows = q.numel() // d
+    q_nope = torch.empty(q.shape[:-1] + (kv_lora_rank,), dtype=torch.float8_e4m3fn, device=q.device)
+    q_scale = torch.empty(q.shape[:-1] + (1,), dtype=torch.float32, device=q.device)
+    q_rope = torch.empty(q.shape[:-1] + (d_rope,), dtype=torch.bfloat16, device=q.device)
+    check(lib.fl_mla_quant_q(q.data_ptr(), rows, kv_lora_rank, d_rope, q_nope.data_ptr(), q_scale.data_ptr(),
+                             q_rope.data_ptr(), stream_ptr(q.device)), "fl_mla_quant_q")
+    return q_nope, q_scale, q_rope
+
+
+def quantize_and_cache_k(key: torch.Tensor, k_lora_cache: torch.Tensor, k_lora_scale_cache: torch.Tensor,
+                         k_rope_cache: torch.Tensor, indices: torch.Tensor, head_dim_v: int = 512) -> None:
+    """In place: per-token quantise key [n,1,576] and scatter into the three caches at `indices` (int32)."""
+    for t, n in ((key, "key"), (k_lora_cache, "k_lora_cache"), (k_lora_scale_cache, "k_lora_scale_cache"),
+                 (k_rope_cache, "k_rope_cache"), (indices, "indices")):
+        _cuda_contig(t, n)
+    _req(key.dtype == torch.bfloat16 and k_rope_cache.dtype == torch.bfloat16, "key / rope cache must be bfloat16")
+    _req(k_lora_cache.dtype in _ONE_BYTE and k_lora_scale_cache.dtype == torch.float32, "bad cache dtypes")
+    _req(indices.dtype == torch.int32, "indices must be int32")
+    d = key.shape[-1]
+    n = key.numel() // d
+    _req(indices.numel() == n, "indices / key length mismatch")
+    num_slots = k_lora_cache.numel() // head_dim_v
+    check(lib.fl_mla_quant_store_k(key.data_ptr(), n, head_dim_v, d - head_dim_v, indices.data_ptr(),
+                                   k_lora_cache.data_ptr(), k_lora_scale_cache.data_ptr(), k_rope_cache.data_ptr(),
+                                   num_slots, stream_ptr(key.device)), "fl_mla_quant_store_k")
+
+
+def dequantize_ckv_fused_indexed(k_lora_fp8: torch.Tensor, k_rope: torch.Tensor, k_scale: torch.Tensor,
+                                 indices: torch.Tensor):
+    """-> (k_lora_deq bf16 [n,1,512], k_rope_deq bf16 [n,1,64]) gathered at `indices`."""
+    for t, n in ((k_lora_fp8, "k_lora_fp8"), (k_rope, "k_rope"), (k_scale, "k_scale"), (indices, "indices")):
+        _cuda_contig(t, n)
+    _req(k_lora_fp8.dtype in _ONE_BYTE and k_rope.dtype == torch.bfloat16 and k_scale.dtype == torch.float32,
+         "bad cache dtypes")
+    idx = indices if indices.dtype == torch.int32 else indices.to(torch.int32)
+    n = idx.numel()
+    d_nope, d_rope = k_lora_fp8.shape[-1], k_rope.shape[-1]
+    num_slots = k_lora_fp8.numel() // d_nope
+    lora = torch.empty((n,) + tuple(k_lora_fp8.shape[1:]), dtype=torch.bfloat16, device=k_rope.device)
+    rope = torch.empty((n,) + tuple(k_rope.shape[1:]), dtype=torch.bfloat16, device=k_rope.device)
+    check(lib.fl_mla_dequant_gather(k_lora_fp8.data_ptr(), k_rope.data_ptr(), k_scale.data_ptr(), idx.data_ptr(), n,
+                                    d_nope, d_rope, num_slots, lora.data_ptr(), rope.data_ptr(),
+                                    stream_ptr(k_rope.device)), "fl_mla_dequant_gather")
+    return lora, rope
+
+
+def _decode(args: FlMlaDecodeArgs, dev):
+    check(lib.fl_mla_decode(ctypes.byref(args), stream_ptr(dev)), "fl_mla_decode")
+
+
+def _common(args, q_like, block_table, cache_seqlens, tile_scheduler_metadata, num_splits, softmax_scale, causal):
+    bs, s_q, h_q = q_like.shape[0], q_like.shape[1], q_like.shape[2]
+    dev = q_like.device
+    for t, n in ((block_table, "block_table"), (cache_seqlens, "cache_seqlens"),
+                 (tile_scheduler_metadata, "tile_scheduler_metadata"), (num_splits, "num_splits")):
+        _req(t.is_cuda and t.dtype == torch.int32, f"{n} must be an int32 device tensor")
+    _req(block_table.dim() == 2 and block_table.stride(1) == 1, "block_table must be [bs, pages] with unit inner stride")
+    _req(cache_seqlens.is_contiguous() and tile_scheduler_metadata.is_contiguous() and num_splits.is_contiguous(),
+         "metadata tensors must be contiguous")
+    _req(block_table.shape[0] >= bs and cache_seqlens.shape[0] >= bs and num_splits.shape[0] >= bs + 1,
+         "metadata tensors shorter than batch")
+    num_parts = tile_scheduler_metadata.shape[0]
+    rows = s_q * h_q
+    args.bs, args.s_q, args.h_q = bs, s_q, h_q
+    args.causal = 1 if causal else 0
+    args.num_parts = num_parts
+    args.softmax_scale = float(softmax_scale)
+    args.block_table = block_table.data_ptr()
+    args.block_table_stride = block_table.stride(0)
+    args.cache_seqlens = cache_seqlens.data_ptr()
+    args.tile_scheduler_metadata = tile_scheduler_metadata.data_ptr()
+    args.num_splits = num_splits.data_ptr()
+    out = torch.empty((bs, s_q, h_q, 512), dtype=torch.bfloat16, device=dev)
+    lse = torch.empty((bs, h_q, s_q), dtype=torch.float32, device=dev)
+    o_accum = torch.empty((bs + num_parts, rows, 512), dtype=torch.float32, device=dev)
+    lse_accum = torch.empty((bs + num_parts, rows), dtype=torch.float32, device=dev)
+    args.out, args.lse, args.o_accum, args.lse_accum = out.data_ptr(), lse.data_ptr(), o_accum.data_ptr(), lse_accum.data_ptr()
+    return out, lse, (o_accum, lse_accum)
+
+
+def flash_mla_ckv_fp8_per_token(q_nope: torch.Tensor, q_rope: torch.Tensor, k_cache_lora: torch.Tensor,
+                                k_cache_rope: torch.Tensor, q_scale: torch.Tensor, k_scale: torch.Tensor,
+                                block_table: torch.Tensor, cache_seqlens: torch.Tensor, head_dim_v: int,
+                                tile_scheduler_metadata: torch.Tensor, num_splits: torch.Tensor,
+                                softmax_scale: Optional[float] = None, causal: bool = False):
+    """Paged MLA decode over the per-token-FP8 latent cache -> (o bf16 [bs,s_q,H,512], lse f32 [bs,H,s_q]).
+    q_nope fp8 [bs,s_q,H,512], q_scale f32 [bs,s_q,H,1], q_rope bf16 [bs,s_q,H,64];
+    k_cache_lora u8/fp8 [pages,64,1,512], k_scale f32 [pages,64,1,1], k_cache_rope bf16 [pages,64,1,64]."""
+    for t, n in ((q_nope, "q_nope"), (q_rope, "q_rope"), (q_scale, "q_scale"), (k_cache_lora, "k_cache_lora"),
+                 (k_cache_rope, "k_cache_rope"), (k_scale, "k_scale")):
+        _cuda_contig(t, n)
+    _req(q_nope.dim() == 4 and q_nope.dtype in _ONE_BYTE, "q_nope must be fp8 [bs,s_q,H,512]")
+    _req(q_rope.dtype == torch.bfloat16 and k_cache_rope.dtype == torch.bfloat16, "rope tensors must be bfloat16")
+    _req(q_scale.dtype == torch.float32 and k_scale.dtype == torch.float32, "scales must be float32")
+    _req(k_cache_lora.dtype in _ONE_BYTE, "k_cache_lora must be a 1-byte dtype")
+    _req(head_dim_v == 512 and q_nope.shape[-1] == 512 and q_rope.shape[-1] == 64, "only kv_lora=512, rope=64")
+    _req(k_cache_lora.shape[1] == PAGE_SIZE, "page size must be 64")
+    if softmax_scale is None:
+        softmax_scale = (q_nope.shape[-1] + q_rope.shape[-1]) ** -0.5
+    a = FlMlaDecodeArgs()
+    a.kv_format = KV_FP8_PER_TOKEN
+    a.d_nope, a.d_rope = 512, 64
+    a.descale_q = a.descale_k = 1.0
+    a.q_nope, a.q_rope, a.q_scale = q_nope.data_ptr(), q_rope.data_ptr(), q_scale.data_ptr()
+    a.k_nope, a.k_rope, a.k_scale = k_cache_lora.data_ptr(), k_cache_rope.data_ptr(), k_scale.data_ptr()
+    a.num_pages = k_cache_lora.shape[0]
+    out, lse, _ws = _common(a, q_nope, block_table, cache_seqlens, tile_scheduler_metadata, num_splits, softmax_scale, causal)
+    _decode(a, q_nope.device)
+    return out, lse
+
+
+def flash_mla_with_kvcache(q: torch.Tensor, k_cache: torch.Tensor, block_table: torch.Tensor,
+                           cache_seqlens: torch.Tensor, head_dim_v: int, tile_scheduler_metadata: torch.Tensor,
+                           num_splits: torch.Tensor, softmax_scale: Optional[float] = None, causal: bool = False,
+                           descale_q: Optional[torch.Tensor] = None, descale_k: Optional[torch.Tensor] = None):
+    """Paged MLA decode over a single 576-wide cache tensor (bf16, or plain fp8 with scalar descales)
+    (flashmla_backend.py:145-175,227-254) -> (o, lse)."""
+    _cuda_contig(q, "q")
+    _cuda_contig(k_cache, "k_cache")
+    _req(q.dim() == 4 and q.shape[-1] == 576 and head_dim_v == 512, "only head_dim 576 / head_dim_v 512")
+    _req(k_cache.shape[1] == PAGE_SIZE, "page size must be 64")
+    if softmax_scale is None:
+        softmax_scale = q.shape[-1] ** -0.5
+    a = FlMlaDecodeArgs()
+    a.d_nope, a.d_rope = 512, 64
+    if q.dtype == torch.bfloat16:
+        _req(k_cache.dtype == torch.bfloat16, "bf16 q needs a bf16 cache")
+        a.kv_format = KV_BF16_576
+        a.descale_q = a.descale_k = 1.0
+    else:
+        _req(q.dtype in _ONE_BYTE and k_cache.dtype in _ONE_BYTE, "fp8 q needs an fp8 cache")
+        a.kv_format = KV_FP8_576
+        # scalar descales are host floats in the C-ABI; the reference passes torch.ones(1) (flashmla_backend.py:237-238)
+        a.descale_q = float(descale_q.item()) if descale_q is not None else 1.0
+        a.descale_k = float(descale_k.item()) if descale_k is not None else 1.0
+    a.q_nope = q.data_ptr()
+    a.k_nope = k_cache.data_ptr()
+    a.num_pages = k_cache.shape[0]
+    out, lse, _ws = _common(a, q, block_table, cache_seqlens, tile_scheduler_metadata, num_splits, softmax_scale, causal)
+    _decode(a, q.device)
+    return out, lse

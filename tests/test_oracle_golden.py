@@ -1,0 +1,115 @@
+"""CPU: pins oracle/*.py against golden vectors produced by the REAL reference (oracle/gen_golden.py)."""
+import numpy as np
+import torch
+
+from helpers import bf16_from_u16, fp8_from_u8, load_golden, rel_mae
+from oracle import gemm_ref, mla_ref
+
+
+def test_kv_quant_bit_exact_vs_reference():
+    g = load_golden("kv_quant_per_token.npz")
+    key = bf16_from_u16(g["key"])
+    loc = torch.from_numpy(g["loc"])
+    k_lora = torch.zeros(g["k_lora"].shape, dtype=torch.uint8)
+    k_scale = torch.zeros(g["k_scale"].shape, dtype=torch.float32)
+    k_rope = torch.zeros(g["k_rope"].shape, dtype=torch.bfloat16)
+    mla_ref.quantize_and_cache_k(key, k_lora, k_scale, k_rope, loc)
+    idx = loc.long()
+    assert np.array_equal(k_lora.numpy()[idx], g["k_lora"][idx])
+    assert np.array_equal(k_scale.numpy()[idx].view(np.uint32), g["k_scale"][idx].view(np.uint32))
+    assert np.array_equal(k_rope.view(torch.int16).numpy().view(np.uint16)[idx], g["k_rope"][idx])
+
+
+def test_dequant_bit_exact_vs_reference():
+    g = load_golden("kv_quant_per_token.npz")
+    lora, rope = mla_ref.dequantize_ckv_fused_indexed(torch.from_numpy(g["k_lora"]), bf16_from_u16(g["k_rope"]),
+                                                      torch.from_numpy(g["k_scale"]), torch.from_numpy(g["gather"]))
+    assert torch.equal(lora.view(torch.int16), bf16_from_u16(g["lora_deq"]).view(torch.int16))
+    assert torch.equal(rope.view(torch.int16), bf16_from_u16(g["rope_deq"]).view(torch.int16))
+
+
+def test_alloc_page_arithmetic_bit_exact():
+    g = load_golden("kv_alloc.npz")
+    free = list(g["free_slots"])
+    r2p = torch.zeros(g["req_to_page"].shape, dtype=torch.int32)
+    for i, (req, need, alloced) in enumerate(g["steps"]):
+        page_num = (alloced + 63) // 64
+        remain_after = max(0, need - (page_num * 64 - alloced))
+        n_new = (remain_after + 63) // 64
+        loc = mla_ref.alloc_kv_loc(r2p[req], free[:n_new], int(need), int(alloced))
+        free = free[n_new:]
+        assert np.array_equal(loc.numpy(), g[f"loc{i}"]), f"step {i}"
+    assert np.array_equal(r2p.numpy(), g["req_to_page"])
+    # token -> slot rule
+    for req in range(r2p.shape[0]):
+        assert mla_ref.kv_slot(r2p, req, 70) == int(r2p[req, 1]) * 64 + 6
+
+
+def _native_case(name):
+    g = load_golden(f"mla_torch_native_{name}.npz")
+    H = int(g["H"])
+    q = bf16_from_u16(g["q"]).view(-1, H, 576)
+    kv = bf16_from_u16(g["kv_buffer_after"])
+    return g, H, q, kv
+
+
+def test_torch_native_decode_matches_reference():
+    for name in ("cfg1", "ragged", "h128"):
+        g, H, q, kv = _native_case(name)
+        o = mla_ref.torch_native_decode(q, kv, torch.from_numpy(g["req_to_token"]), torch.arange(q.shape[0]),
+                                        torch.from_numpy(g["seq_lens"]), float(g["scaling"]))
+        ref = bf16_from_u16(g["o"])
+        # same torch, same loop: normally bit-identical; allow bf16 rounding for other host CPUs' SDPA kernels
+        assert (o.float() - ref.float()).abs().max() < 2e-2, name
+        assert rel_mae(o, ref) < 2e-3, name
+
+
+def test_exact_attention_oracle_matches_reference_backend():
+    """mla_decode_exact (fp64, page-table gather) vs the reference's TorchNativeAttnBackend output."""
+    for name in ("cfg1", "ragged", "h128"):
+        g, H, q, kv = _native_case(name)
+        bs = q.shape[0]
+        o, lse = mla_ref.mla_decode_exact(q.view(bs, 1, H, 576).float(), kv.view(-1, 576).float(),
+                                          torch.from_numpy(g["block_table"]), torch.from_numpy(g["seq_lens"]),
+                                          float(g["scaling"]), 512, causal=True)
+        ref = bf16_from_u16(g["o"]).view(bs, 1, H, 512)
+        assert (o.float() - ref.float()).abs().max() < 2e-2, name  # reference computes in bf16
+        assert torch.isfinite(lse).all()
+
+
+def test_gemm_oracles_match_reference():
+    g = load_golden("gemm_block_fp8.npz")
+    xq, xs = gemm_ref.per_token_group_quant_fp8(bf16_from_u16(g["quant_x"]), 128)
+    assert np.array_equal(xq.view(torch.uint8).numpy(), g["quant_q"])
+    assert np.array_equal(xs.numpy().view(np.uint32), g["quant_s"].view(np.uint32))
+    C = gemm_ref.block_fp8_matmul(fp8_from_u8(g["mm_A"]), fp8_from_u8(g["mm_B"]), torch.from_numpy(g["mm_As"]),
+                                  torch.from_numpy(g["mm_Bs"]))
+    assert rel_mae(C, bf16_from_u16(g["mm_C"])) < 1e-3
+    act = gemm_ref.silu_and_mul(bf16_from_u16(g["silu_x"]))
+    assert torch.equal(act.view(torch.int16), bf16_from_u16(g["silu_out"]).view(torch.int16))
+    out = gemm_ref.moe_fp8_block(bf16_from_u16(g["moe_a"]), fp8_from_u8(g["moe_w1"]), fp8_from_u8(g["moe_w2"]),
+                                 torch.from_numpy(g["moe_w1_s"]), torch.from_numpy(g["moe_w2_s"]),
+                                 torch.from_numpy(g["moe_topk_w"]), torch.from_numpy(g["moe_topk_ids"]).long())
+    assert rel_mae(out, bf16_from_u16(g["moe_out"])) < 2e-2
+
+
+def test_grouped_gemm_variants_agree():
+    g = torch.Generator().manual_seed(5)
+    E, N, K = 3, 256, 256
+    counts = [5, 0, 9]
+    M = sum(counts)
+    A = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    Aq, As = gemm_ref.per_token_group_quant_fp8(A, 128)
+    W = ((torch.rand(E, N, K, generator=g) - 0.5) * 896).clamp(-448, 448).to(torch.float8_e4m3fn)
+    Ws = torch.rand(E, N // 128, K // 128, generator=g) * 1e-2
+    ex = torch.tensor([0, 5, 5, 14], dtype=torch.int32)
+    o1 = gemm_ref.grouped_gemm_offset(Aq, As, W, Ws, ex)
+    mi = torch.tensor([0] * 5 + [2] * 9)
+    o2 = gemm_ref.grouped_gemm_contiguous(Aq, As, W, Ws, mi)
+    assert torch.equal(o1, o2)
+    Am = torch.zeros(E, 16, K, dtype=torch.float8_e4m3fn)
+    Asm = torch.zeros(E, 16, K // 128)
+    Am[0, :5], Asm[0, :5] = Aq[:5], As[:5]
+    Am[2, :9], Asm[2, :9] = Aq[5:], As[5:]
+    o3 = gemm_ref.grouped_gemm_masked(Am, Asm, W, Ws, torch.tensor(counts))
+    assert torch.equal(o3[0, :5], o1[:5]) and torch.equal(o3[2, :9], o1[5:])

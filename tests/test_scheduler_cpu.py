@@ -1,0 +1,46 @@
+"""CPU: properties of the split-KV tile scheduler statement (oracle/mla_ref.py:get_mla_metadata = the Python
+statement of csrc/mla_metadata.hip; the GPU test compares the two bit-exactly)."""
+import random
+
+from oracle import mla_ref
+
+
+def _coverage(seqlens, parts):
+    meta, ns = mla_ref.get_mla_metadata(seqlens, parts)
+    bs = len(seqlens)
+    nt = [((L + 63) // 64) if L > 0 else 0 for L in seqlens]
+    seen = [[0] * n for n in nt]
+    touched = [0] * bs
+    for p in range(parts):
+        b0, t0, b1, t1, s0 = (int(x) for x in meta[p, :5])
+        req, tile, split = b0, t0, s0
+        while req < bs and (req < b1 or (req == b1 and t1 > 0)):
+            te = nt[req] if req < b1 else min(t1, nt[req])
+            for t in range(tile, te):
+                seen[req][t] += 1
+            assert split == touched[req], "split index must count the parts that touched the request before"
+            touched[req] += 1
+            req, tile, split = req + 1, 0, 0
+    assert all(all(c == 1 for c in row) for row in seen), "every tile exactly once"
+    for b in range(bs):
+        assert ns[b + 1] - ns[b] == max(touched[b], 1) == touched[b], (b, touched[b], ns)
+    assert ns[bs] <= bs + parts
+    return meta, ns
+
+
+def test_uniform_decode_batch_has_no_splits():
+    meta, ns = _coverage([4096] * 128, 128)
+    assert all(ns[b + 1] - ns[b] == 1 for b in range(128))
+
+
+def test_random_ragged():
+    rnd = random.Random(0)
+    for _ in range(200):
+        bs = rnd.randint(1, 40)
+        lens = [rnd.choice([0, 1, 63, 64, 65, rnd.randint(1, 9000)]) for _ in range(bs)]
+        _coverage(lens, rnd.choice([1, 2, 7, 64, 128, 256]))
+
+
+def test_small_batch_splits_long_sequence():
+    meta, ns = _coverage([16384], 128)
+    assert ns[1] > 64  # one long request is spread over many CUs
