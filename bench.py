@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json metric on MI355X: DeepSeek-V3 MLA decode, per-token FP8 KV, bs=128 seq=4096, TP=1.
+
+One "step" = one decode token for the whole batch through the MLA hot path of all 61 layers: per layer
+K5 (quantise+store the new latent K), K4 (quantise Q), K1 (paged FP8 MLA decode + split combine), each layer with
+its OWN KV cache (61 x 338 MB = 20.6 GB resident in HBM, so nothing is re-served from the 256 MB Infinity Cache).
+All inputs are resident in HBM before the timed region.  Multi-GPU = DP-attention (each rank owns its
+requests and pages, no data-path collective): weak scaling, value = total tokens/s over all ranks.
+
+Prints ONE JSON line (rank 0) with `roofline` (live HIP-event timing of the dominant kernel on its launch stream)
+and `cpu_baseline` (the oracle's restatement of the reference's torch-native CPU attention path, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "sglang-fluentllm_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+LAYERS = 61
+BS, SEQ, H, S_Q = 128, 4096, 128, 1
+SCALE = 192 ** -0.5
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling ~6290 GB/s
+
+
+def algorithmic_bytes(bs, seq, h, s_q):
+    """per (request, layer): seq*644 KV + s_q*H*644 Q (after K4) + s_q*H*1024 out + 4*ceil(seq/64)."""
+    return bs * (seq * 644 + s_q * h * 644 + s_q * h * 1024 + 4 * ((seq + 63) // 64))
+
+
+def build_workload(dev, layers, bs, seq, h, seed):
+    import flash_mla_fp8 as fm
+
+    g = torch.Generator(device=dev).manual_seed(seed)
+    npg = (seq + 63) // 64
+    pages = bs * npg + 1
+    slots = pages * 64
+    key = torch.randn(slots, 1, 576, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    caches = []
+    for l in range(layers):
+        k_lora = torch.empty(slots, 1, 512, dtype=torch.uint8, device=dev)
+        k_scale = torch.empty(slots, 1, 1, dtype=torch.float32, device=dev)
+        k_rope = torch.empty(slots, 1, 64, dtype=torch.bfloat16, device=dev)
+        # same statistics per layer, different physical content (rolled) — values matter only for DVFS realism
+        idx = ((torch.arange(slots, device=dev, dtype=torch.int64) + 64 * 7 * l) % slots).to(torch.int32)
+        fm.quantize_and_cache_k(key, k_lora, k_scale, k_rope, idx, 512)
+        caches.append((k_lora, k_scale, k_rope))
+    del key
+    perm = torch.randperm(pages - 1, device=dev, generator=g).to(torch.int32) + 1  # page 0 = padding page, unused
+    block_table = perm.view(bs, npg).contiguous()
+    seqlens = torch.full((bs,), seq, dtype=torch.int32, device=dev)
+    q = torch.randn(bs, S_Q, h, 576, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    k_new = torch.randn(bs, 1, 576, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    # slot of the newest token of every request (the decode step writes it before attending: flashmla_backend.py:188-197)
+    out_loc = (block_table[:, (seq - 1) // 64].to(torch.int64) * 64 + (seq - 1) % 64).to(torch.int32)
+    return dict(caches=caches, block_table=block_table, seqlens=seqlens, q=q, k_new=k_new, out_loc=out_loc, pages=pages)
+
+
+def layer_call(fm, wl, l, meta, ns):
+    k_lora, k_scale, k_rope = wl["caches"][l]
+    pages = wl["pages"]
+    fm.quantize_and_cache_k(wl["k_new"], k_lora, k_scale, k_rope, wl["out_loc"], 512)
+    qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
+    return fm.flash_mla_ckv_fp8_per_token(qn, qr, k_lora.view(pages, 64, 1, 512), k_rope.view(pages, 64, 1, 64), qs,
+                                          k_scale.view(pages, 64, 1, 1), wl["block_table"], wl["seqlens"], 512, meta, ns,
+                                          SCALE, True)
+
+
+def cpu_baseline(threads_cap=None):
+    """The reference's CPU path for this op (torch_native_backend.py:309-343) as restated in oracle/mla_ref.py,
+    bf16 KV, same shape per request (H=128, seq=4096), bounded sample of requests."""
+    from oracle import mla_ref
+
+    ncores = os.cpu_count() or 1
+    nthreads = min(ncores, threads_cap) if threads_cap else ncores
+    torch.set_num_threads(nthreads)
+    g = torch.Generator().manual_seed(0)
+    bs_s = 2
+    npg = SEQ // 64
+    slots = (bs_s * npg + 1) * 64
+    kv = torch.randn(slots, 1, 576, generator=g).to(torch.bfloat16)
+    perm = torch.randperm(bs_s * npg, generator=g) + 1
+    r2t = (perm.view(bs_s, npg, 1) * 64 + torch.arange(64).view(1, 1, 64)).view(bs_s, -1).to(torch.int32)
+    q = torch.randn(bs_s, H, 576, generator=g).to(torch.bfloat16)
+    seq = torch.full((bs_s,), SEQ, dtype=torch.int64)
+    args = (q, kv, r2t, torch.arange(bs_s), seq, SCALE)
+    mla_ref.torch_native_decode(*args)  # warm-up
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_all) < 25.0:
+        t0 = time.perf_counter()
+        mla_ref.torch_native_decode(*args)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    per_req_layer = t / bs_s
+    return {"value": 1.0 / (per_req_layer * LAYERS), "unit": "tokens/s", "cores": nthreads, "kind": "port",
+            "sample": f"oracle.mla_ref.torch_native_decode (reference torch_native_backend.py:309-343 restated), bf16 KV, "
+                      f"bs={bs_s} of 128, H={H}, seq={SEQ}, median of {len(times)} layer-calls, {per_req_layer*1e3:.1f} ms per "
+                      f"request-layer, x{LAYERS} layers"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--layers", type=int, default=LAYERS, help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with WORLD_SIZE={a.gpus} (got {world})")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import flash_mla_fp8 as fm
+
+    layers = a.layers
+    wl = build_workload(dev, layers, BS, SEQ, H, seed=1234 + rank)
+    meta, ns = fm.get_mla_metadata(wl["seqlens"], S_Q * H, 1)
+    torch.cuda.synchronize()
+
+    def step():
+        for l in range(layers):
+            layer_call(fm, wl, l, meta, ns)
+
+    # eager warm-up (also sizes the caching allocator), then capture one step in a hipGraph like the reference's
+    # decode path (model_executor/cuda_graph_runner.py:433-434)
+    step()
+    torch.cuda.synchronize()
+    graph = None
+    if not a.no_graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+    run = graph.replay if graph is not None else step
+    for _ in range(a.warmup):
+        run()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    tokens_per_s = world * BS / (ms_per_step * 1e-3) * (LAYERS / layers)
+
+    # ---- roofline of the dominant kernel: K1 alone, HIP events on the launch stream (torch's current stream) ----
+    roof = None
+    if rank == 0:
+        pages = wl["pages"]
+        qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
+
+        def k1(l):
+            k_lora, k_scale, k_rope = wl["caches"][l]
+            fm.flash_mla_ckv_fp8_per_token(qn, qr, k_lora.view(pages, 64, 1, 512), k_rope.view(pages, 64, 1, 64), qs,
+                                           k_scale.view(pages, 64, 1, 1), wl["block_table"], wl["seqlens"], 512, meta, ns,
+                                           SCALE, True)
+
+        for l in range(layers):
+            k1(l)
+        torch.cuda.synchronize()
+        reps = 3
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            for l in range(layers):
+                k1(l)
+        e1.record()
+        torch.cuda.synchronize()
+        per_launch_s = e0.elapsed_time(e1) * 1e-3 / (reps * layers)
+        alg = algorithmic_bytes(BS, SEQ, H, S_Q)
+        achieved = alg / per_launch_s / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "mla_decode_fp8_kernel(+mla_combine_kernel)", "us_per_launch": round(per_launch_s * 1e6, 2),
+                "algorithmic_bytes_per_launch": alg}
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "decode tokens/s (MLA-attention-bound, 61 layers) + achieved HBM GB/s, DeepSeek-V3 MLA bs=128 seq=4k",
+            "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp8_e4m3 (KV, Q, P) x fp8 -> f32 acc; bf16 rope; bf16 out", "data": "synthetic",
+            "config": {"workload": "DeepSeek-V3 MLA decode, per-token fp8 KV, bs=128/GPU seq=4096 H=128 (TP=1), page=64, "
+                                   "pages randomly permuted, 61 layers x (K5 store + K4 quant-q + K1 decode) per step",
+                       "bs_per_gpu": BS, "seq_len": SEQ, "heads": H, "layers_per_step": layers,
+                       "parallelism": f"dp{world} (DP-attention, no data-path collective)", "hipgraph": graph is not None},
+            "roofline": roof, "cpu_baseline": cpu}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

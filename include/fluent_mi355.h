@@ -86,7 +86,7 @@ typedef struct FlMlaDecodeArgs {
   void* out;                /* bf16 [bs,s_q,h_q,d_nope] */
   float* lse;               /* f32 [bs,h_q,s_q] natural-log LSE */
   float* o_accum;           /* f32 [bs+num_parts, s_q*h_q, d_nope] split-KV workspace (caller-owned) */
-  float* lse_accum;         /* f32 [bs+num_parts, s_q*h_q] */
+  float* lse_accum;         /* f32 [bs+num_parts, s_q*h_q, 2] {weight LSE, exact LSE} workspace */
 } FlMlaDecodeArgs;
 
 int fl_mla_decode(const FlMlaDecodeArgs* args, fl_stream_t stream);

@@ -240,3 +240,75 @@ def get_mla_metadata(cache_seqlens, num_parts: int, page_size: int = PAGE_SIZE):
         meta[p, 2], meta[p, 3] = req, tile
     assert req == bs
     return meta, num_splits
+
+
+# --------------------------------------------------------------------------------------
+# Bit-level statement of OUR kernel's arithmetic (csrc/mla_decode_fp8.hip) — NOT of the reference.
+# The exact oracle above bounds the end-to-end error (FP8 tolerance); this one pins the design:
+# per page, the two 32-token halves keep independent integer references m_W = ceil(running max
+# of y)+2, y = s*log2e + log2(k_scale[t]); P' = 2^(y - m_W + 8) is rounded to e4m3 (RNE);
+# O accumulates 2^(m_W - M) * P'_q * k8 (exact powers of two).  Two normalisers per half: lq_W sums
+# the ROUNDED P'_q/k_scale[t] (divides O: the weights of the quantised numerator sum to exactly 1,
+# so e.g. a 1-token sequence returns its latent exactly), lx_W sums the unrounded P'/k_scale[t]
+# (exact LSE).  Differences to the GPU are fp32-vs-fp64 accumulation and exp2 ulps only.
+# --------------------------------------------------------------------------------------
+def mla_decode_fp8_per_token_emulated(q_nope, q_scale, q_rope, k_lora, k_scale, k_rope, block_table,
+                                      cache_seqlens, softmax_scale, causal=True, page_size=PAGE_SIZE):
+    bs, s_q, H, dn = q_nope.shape
+    rows = s_q * H
+    q8 = q_nope.view(torch.float8_e4m3fn).double().reshape(bs, rows, dn)
+    qr = q_rope.double().reshape(bs, rows, -1)
+    qs = (q_scale.float().reshape(bs, rows) * torch.tensor(softmax_scale * 1.4426950408889634, dtype=torch.float32))
+    k8 = k_lora.view(torch.float8_e4m3fn).reshape(-1, dn).double()
+    kr = k_rope.reshape(-1, k_rope.shape[-1]).double()
+    ks = k_scale.reshape(-1).float()
+    out = torch.zeros(bs, rows, dn, dtype=torch.float64)
+    lse = torch.full((bs, rows), -math.inf, dtype=torch.float64)
+    NEG = -16384.0
+    for b in range(bs):
+        L = int(cache_seqlens[b])
+        if L <= 0:
+            continue
+        j = torch.arange(rows) // H
+        L_row = (L - (s_q - 1 - j)) if causal else torch.full((rows,), L)
+        O = torch.zeros(rows, dn, dtype=torch.float64)
+        M = torch.full((rows,), NEG, dtype=torch.float64)
+        mW = [torch.full((rows,), NEG, dtype=torch.float64) for _ in range(2)]
+        lW = [torch.zeros(rows, dtype=torch.float64) for _ in range(2)]   # exact (LSE)
+        lQ = [torch.zeros(rows, dtype=torch.float64) for _ in range(2)]   # from rounded P (normalises O)
+        for pg in range((L + page_size - 1) // page_size):
+            page = int(block_table[b, pg])
+            Pq, sc = [], []
+            for W in range(2):
+                t0 = pg * page_size + 32 * W
+                slots = page * page_size + 32 * W + torch.arange(32)
+                valid_tok = (t0 + torch.arange(32)) < L
+                ksw = torch.where(valid_tok, ks[slots], torch.ones(32))
+                acc = (q8[b] @ k8[slots].T + qr[b] @ kr[slots].T).float()                 # [rows, 32]
+                y = torch.addcmul(torch.log2(ksw)[None, :], acc * qs[b][:, None], ksw[None, :]).double()
+                mask = (t0 + torch.arange(32))[None, :] >= L_row[:, None]
+                y = torch.where(mask | torch.isnan(y), torch.full_like(y, -math.inf), y)
+                tmax = y.max(dim=1).values
+                m_new = torch.where(tmax > mW[W], torch.ceil(tmax) + 2.0, mW[W])
+                lW[W] = lW[W] * torch.exp2(mW[W] - m_new)
+                lQ[W] = lQ[W] * torch.exp2(mW[W] - m_new)
+                mW[W] = m_new
+                P = torch.exp2(y - m_new[:, None] + 8.0)
+                lW[W] = lW[W] + (P / ksw[None, :].double()).sum(1)
+                Pq.append(P.float().to(torch.float8_e4m3fn).double())
+                lQ[W] = lQ[W] + (Pq[-1] / ksw[None, :].double()).sum(1)
+                sc.append(slots)
+            M_new = torch.maximum(M, torch.maximum(mW[0], mW[1]))
+            O = O * torch.exp2(M - M_new)[:, None]
+            M = M_new
+            for W in range(2):
+                v = k8[sc[W]].clone()
+                v[(pg * page_size + 32 * W + torch.arange(32)) >= L] = 0.0   # zero-filled tail rows
+                O = O + torch.exp2(torch.clamp(mW[W] - M, min=-127.0))[:, None] * (Pq[W] @ v)
+        l = lW[0] * torch.exp2(mW[0] - M) + lW[1] * torch.exp2(mW[1] - M)
+        lq = lQ[0] * torch.exp2(mW[0] - M) + lQ[1] * torch.exp2(mW[1] - M)
+        ok = l > 0
+        okq = lq > 0
+        out[b][okq] = O[okq] / lq[okq][:, None]
+        lse[b][ok] = (torch.log2(l[ok]) + M[ok] - 8.0) * math.log(2.0)
+    return out.reshape(bs, s_q, H, dn), lse.reshape(bs, s_q, H).permute(0, 2, 1).contiguous()

@@ -9,22 +9,30 @@
 //   o[r,:]  = sum_t softmax_t(s[r,:]) * k_scale[t] * k8[t,:512]          (V = dequantised latent)
 //
 // MI355X mapping ("SwapAB": tokens on the MFMA M side, query rows on the N side):
-//   * one workgroup = 2*WH waves, one wave per SIMD, 512 registers per lane.  Wave (wh, wt) owns 32 query rows
-//     (wh) and every second 64-token page of the workgroup's page list (wt); the two token-waves of a row group are
-//     merged once per request through LDS, so a full request needs no split-KV round trip through HBM.
-//   * S^T[64 tok x 32 rows] = K_tile · Q^T on v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 e4m3, unit E8M0 scales, the
-//     2x-rate MX path) + 32x32x16 bf16 for the 64 rope dims.  Each lane then holds ONE query row (lane&31) and 32
-//     tokens: the online-softmax row reductions are in-register plus a single cross-half exchange.
-//   * P is re-quantised to fp8 in registers, already in the B-operand layout of the PV MFMA (the contraction order
-//     over tokens is free, so V^T is gathered in the same token order): O^T[512 x 32 rows] += V^T · P^T, V^T read
-//     from the SAME LDS bytes as K through ds_read_b64_tr_b8 (hardware byte transpose).
-//   * k_scale[t] is folded into the exponent: y = s*log2e + log2(k_scale[t]), running max over y, P' = 2^(y-m+8)
-//     (fp8 range [2^-9, 256]), l accumulates P'/k_scale[t] in fp32.  No per-tile rescale of V is needed.
-//   * HBM -> LDS by global_load_lds (16 B/lane, 1 KiB per wave instruction) into a 4-slot ring of 32 KiB pages,
-//     XOR-swizzled on the SOURCE address (16-B chunk c of token T lands at chunk c ^ (T&15)) so that both the
-//     K-operand ds_read_b128 and the V^T ds_read_b64_tr_b8 are bank-conflict free.  Tokens beyond the sequence end
-//     are sourced from a zero line (never NaN * 0 in the PV MFMA).  Rope (8 KiB/page) and the raw scales go
-//     straight to VGPRs one page ahead (they are waited for by the ring barrier's vmcnt(0), never earlier).
+//   * one workgroup = 2*NRG waves (one per SIMD), NRG row groups of 32 query rows; every wave of the workgroup works
+//     on the SAME 64-token page.  Wave (rg, W) computes S^T[32 tok x 32 rows] = K[32W..32W+31] · Q_rg^T on
+//     v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 e4m3, the 2x-rate MX path; + 32x32x16 bf16 for the 64 rope dims): each
+//     lane then holds ONE query row (lane&31), so the online-softmax reductions are in-register plus one cross-half
+//     exchange.  The same wave owns the d-half [256W, 256W+256) of O^T = V^T · P^T (8 accumulator tiles, 128 VGPRs).
+//   * the two waves of a row group keep INDEPENDENT integer softmax references m_W (ceil of the running max of
+//     y = s*log2e + log2 k_scale[t], which also folds the per-token V scale into P).  P' = 2^(y - m_W + 8) is
+//     re-quantised to fp8 and exchanged through 1 KiB of LDS; the PV MFMA reconciles the two references for free with
+//     its E8M0 block scales 2^(m_W - M) (M = reference of the O accumulator), so no cross-wave max exchange and
+//     exactly ONE s_barrier per page.  Two fp32 normalisers per wave, merged once per request: the ROUNDED P'/k_scale
+//     (divides O: quantised weights sum to exactly 1) and the unrounded one (exact LSE).
+//     (Measured on gfx950: MX block b of the 32x32x64 B operand = bytes [16b,16b+16) of BOTH lane halves, its scale
+//     comes from lane n+32b — so every lane keeps its own 16 P bytes in registers as block W and only fetches the
+//     partner lane's 16 bytes.)
+//   * V^T is read from the SAME LDS bytes as K through ds_read_b64_tr_b8 (hardware byte transpose), in the token
+//     order in which P sits in the B operand (the contraction order over tokens is free).
+//   * HBM -> LDS exclusively by global_load_lds (LDS-DMA, 16 B/lane, 1 KiB per wave instruction): a 4-slot ring of
+//     32 KiB latent pages + 2-slot rings for rope (8 KiB) and raw scales, XOR-swizzled on the SOURCE address so that
+//     ds_read_b128 (K operand, rope) and ds_read_b64_tr_b8 (V^T) are bank-conflict free.  Waits are counted
+//     (s_waitcnt vmcnt(8) + raw s_barrier): two pages stay in flight across every barrier.  The per-page body is one
+//     inlined function whose LDS regions are distinct __restrict__ parameters — otherwise hipcc's waitcnt pass
+//     assumes every ds_read may alias the in-flight LDS-DMA and drains it with vmcnt(0).
+//   * rows past the sequence end are zero-filled in LDS by the consumers (P' is exactly 0 there, but 0*NaN from stale
+//     fp8 NaN patterns would poison the PV MFMA).
 //
 // Algorithmic bytes per (request, layer call): seq*644 (KV) + s_q*h_q*(644 + 1024) (Q in, O out) + 4*ceil(seq/64).
 #include "fl_common.h"
@@ -35,39 +43,45 @@ constexpr int kPage = FL_MLA_PAGE;            // 64 tokens per page / tile
 constexpr int kDN = 512;                      // latent (nope) dims, fp8
 constexpr int kDR = 64;                       // rope dims, bf16
 constexpr int kSlotBytes = kPage * kDN;       // 32 KiB
+constexpr int kRopeBytes = kPage * kDR * 2;   // 8 KiB
 constexpr int kRingSlots = 4;
-constexpr int kRingBytes = kRingSlots * kSlotBytes;  // 128 KiB
-constexpr int kScaleScratchPerWave = 3 * kPage * 4;  // ks, log2 ks, 1/ks
-constexpr int kMaxWaves = 4;
-constexpr int kLdsBytes = kRingBytes + kMaxWaves * kScaleScratchPerWave;
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kPShift = 4.0f;               // P' = 2^(y - m + 4): 16 at the running reference ...
-constexpr float kRescaleThr = 4.0f;           // ... which may lag the true max by <= 4 (P' <= 256 < 448, T13 defer-max)
-constexpr int kUnitScale = 0x7F7F7F7F;        // E8M0 127 = 2^0
 
-__device__ __attribute__((aligned(16))) const uint32_t g_zero_line[4] = {0, 0, 0, 0};
+// ---- LDS map (one __shared__ array) ----
+constexpr int kOffRing = 0;                                   // 4 x 32 KiB
+constexpr int kOffRope = kOffRing + kRingSlots * kSlotBytes;  // 2 x 8 KiB
+constexpr int kOffScale = kOffRope + 2 * kRopeBytes;          // 2 x 64 f32 raw k_scale
+constexpr int kOffScratch = kOffScale + 2 * kPage * 4;        // 4 waves x {ks, log2 ks, 1/ks} x 32 tokens
+constexpr int kScratchPerWave = 3 * 32 * 4;
+constexpr int kOffPbuf = kOffScratch + 4 * kScratchPerWave;   // [parity 2][rg 2][W 2][64 lanes][16 B]
+constexpr int kPbufPerParity = 2 * 2 * 32 * 32;
+constexpr int kOffRef = kOffPbuf + 2 * kPbufPerParity;        // [parity 2][rg 2][W 2][32 rows] f32
+constexpr int kRefPerParity = 2 * 2 * 32 * 4;
+constexpr int kLdsBytes = kOffRef + 2 * kRefPerParity;
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kPShift = 8.0f;               // P' = 2^(y - m_W + 8) <= 256 < 448
+constexpr float kRefHeadroom = 2.0f;          // new reference = ceil(max) + 2: fewer reference moves
+constexpr float kNegRef = -16384.0f;          // "no reference yet" (finite, integer)
+constexpr int kUnitScale = 0x7F;              // E8M0 127 = 2^0
+constexpr int kDmaNopePerTile = 32;           // 1-KiB pieces per page
 
 struct Params {
   int bs, s_q, h_q, rows, causal, num_parts, row_groups;
   float scale_log2e;
-  const uint8_t* q_nope;
-  const uint16_t* q_rope;
-  const float* q_scale;
-  const uint8_t* k_nope;
-  const uint16_t* k_rope;
-  const float* k_scale;
   long long num_pages;
-  const int32_t* block_table;
   long long bt_stride;
-  const int32_t* seqlens;
-  const int32_t* meta;
-  const int32_t* num_splits;
   uint16_t* out;
   float* lse;
   float* o_accum;
   float* lse_accum;
 };
 
+#ifdef FL_MLA_DEBUG
+__device__ int* g_dbg = nullptr;   // debug builds only: set by fl_mla_debug_set_buffer
+#endif
+
+typedef float float2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -82,37 +96,278 @@ __device__ __forceinline__ v8i make_v8i(uint4 a, uint4 b) {
   return r;
 }
 
-// Read-only inputs are separate `const __restrict__` kernel arguments (not struct members) so that hipcc proves them
-// invariant: wave-uniform reads (page ids, lengths, scheduler rows) become s_load (lgkmcnt) instead of vector loads
-// whose vmcnt(0) would drain the LDS-DMA queue between every piece.
-template <int WH>
-__global__ __launch_bounds__(128 * WH, 1) void mla_decode_fp8_kernel(
+// Per-lane constants of the LDS access patterns (computed once per kernel).
+struct LaneConst {
+  int lane, li, lh;
+  int kb[2][4];    // K operand: byte offset inside a slot, [e][s&3]; + (s>>2)*256 immediate; + W*16384
+  int rb[4];       // rope operand: byte offset inside a rope slot, [s]
+  int vb[8];       // V^T tr8 source: byte offset inside a slot, [(jb&3) | (jb>>2)<<2]; + u immediates
+};
+
+struct ReqState {
+  v16f o[8];
+  float l_run, lq_run, m_w, m_o;   // own exact / rounded-P normalisers, own integer reference, reference of O
+};
+
+// One page of one request for one wave.  All LDS regions are distinct __restrict__ parameters (see file header).
+template <int NRG>
+__device__ __forceinline__ void tile_body(
+    ReqState& st, const LaneConst& lc, const v8i (&qn)[8], const v8bf (&qr)[4], const float qs, const int W,
+    const int rg, const int wave,
+    // ---- LDS regions consumed now
+    const uint8_t* __restrict__ rd_nope, const uint8_t* __restrict__ rd_rope, const float* __restrict__ rd_scale,
+    float* __restrict__ scratch, uint8_t* __restrict__ pbuf, float* __restrict__ refbuf,
+    // ---- LDS regions filled by the DMA issued in this call (never read in this call)
+    uint8_t* __restrict__ dma_nope, uint8_t* __restrict__ dma_rope, float* __restrict__ dma_scale,
+    // ---- DMA sources (global; null = nothing to issue)
+    const uint8_t* __restrict__ src_nope, const uint16_t* __restrict__ src_rope, const float* __restrict__ src_scale,
+    // ---- page geometry
+    const int tok0, const int L, const int L_row, const int L_min, const bool more_in_flight) {
+  constexpr int NW = 2 * NRG;
+  constexpr int kNopePerWave = kDmaNopePerTile / NW;
+  constexpr int kRopePerWave = 8 / NW;
+  const int lane = lc.lane, li = lc.li, lh = lc.lh;
+
+  // ---- tail of the sequence: zero the rows past the end (every wave, all rows it may read) ----
+  if (tok0 + kPage > L) {
+    const int nvalid = L - tok0;
+    uint8_t* wr = const_cast<uint8_t*>(rd_nope);
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (int T = nvalid + lh; T < kPage; T += 2)
+      *reinterpret_cast<uint4*>(wr + T * kDN + li * 16) = make_uint4(0, 0, 0, 0);
+  }
+
+  // ---- per-token scale preprocessing: lanes 0..31 handle the 32 tokens of this wave's half ----
+  {
+    float ks = rd_scale[32 * W + li];
+    if (tok0 + 32 * W + li >= L || !(ks > 0.f) || !(ks < 3.0e38f)) ks = 1.f;
+    if (lh == 0) {
+      scratch[li] = ks;
+      scratch[32 + li] = __builtin_amdgcn_logf(ks);
+      scratch[64 + li] = __builtin_amdgcn_rcpf(ks);
+    }
+  }
+
+  // ---- A. S^T[32 tok x 32 rows] = K[32W + ..] · Q^T ----
+  v16f acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  {
+    const uint8_t* rp = rd_rope + W * (32 * kDR * 2);
+    uint4 ra[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ra[s] = *reinterpret_cast<const uint4*>(rp + lc.rb[s]);
+    const uint8_t* kp = rd_nope + W * (32 * kDN);
+    uint4 ka[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      ka[s][0] = *reinterpret_cast<const uint4*>(kp + lc.kb[0][s & 3] + (s >> 2) * 256);
+      ka[s][1] = *reinterpret_cast<const uint4*>(kp + lc.kb[1][s & 3] + (s >> 2) * 256);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ra[s]), qr[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc, 0, 0, 0,
+                                                            kUnitScale, 0, kUnitScale);
+  }
+
+  // ---- B. local online softmax on y = s*log2e + log2(k_scale[t]); tokens of lane: 32W + 8g + 4lh + e ----
+  const bool need_mask = (tok0 + kPage > L_min);
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int tb = g * 8 + lh * 4;
+    const float4 ks4 = *reinterpret_cast<const float4*>(scratch + tb);
+    const float4 lk4 = *reinterpret_cast<const float4*>(scratch + 32 + tb);
+    const float ksv[4] = {ks4.x, ks4.y, ks4.z, ks4.w};
+    const float lkv[4] = {lk4.x, lk4.y, lk4.z, lk4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float y = fmaf(acc[g * 4 + e] * qs, ksv[e], lkv[e]);
+      if (need_mask && (tok0 + 32 * W + tb + e >= L_row)) y = -INFINITY;
+      if (!(y == y)) y = -INFINITY;   // NaN can only come from garbage beyond the row's limit
+      acc[g * 4 + e] = y;
+      tmax = fmaxf(tmax, y);
+    }
+  }
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+  {
+    const float m_new = tmax > st.m_w ? ceilf(tmax) + kRefHeadroom : st.m_w;
+    const float f = __builtin_amdgcn_exp2f(st.m_w - m_new);   // exactly 1 when the reference did not move
+    st.l_run *= f;
+    st.lq_run *= f;
+    st.m_w = m_new;
+  }
+  uint4 own_p;
+  {
+    const float moff = kPShift - st.m_w;
+    int pk[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int tb = g * 8 + lh * 4;
+      const float4 ik4 = *reinterpret_cast<const float4*>(scratch + 64 + tb);
+      const float e0 = __builtin_amdgcn_exp2f(acc[g * 4 + 0] + moff);
+      const float e1 = __builtin_amdgcn_exp2f(acc[g * 4 + 1] + moff);
+      const float e2 = __builtin_amdgcn_exp2f(acc[g * 4 + 2] + moff);
+      const float e3 = __builtin_amdgcn_exp2f(acc[g * 4 + 3] + moff);
+      st.l_run = fmaf(e0, ik4.x, st.l_run);
+      st.l_run = fmaf(e1, ik4.y, st.l_run);
+      st.l_run = fmaf(e2, ik4.z, st.l_run);
+      st.l_run = fmaf(e3, ik4.w, st.l_run);
+      int v = __builtin_amdgcn_cvt_pk_fp8_f32(e0, e1, 0, false);
+      pk[g] = __builtin_amdgcn_cvt_pk_fp8_f32(e2, e3, v, true);
+      // the ROUNDED weights normalise O (numerator and denominator use the same weights: they sum to exactly 1)
+      const float2v d01 = __builtin_amdgcn_cvt_pk_f32_fp8(pk[g], false);
+      const float2v d23 = __builtin_amdgcn_cvt_pk_f32_fp8(pk[g], true);
+      st.lq_run = fmaf(d01[0], ik4.x, st.lq_run);
+      st.lq_run = fmaf(d01[1], ik4.y, st.lq_run);
+      st.lq_run = fmaf(d23[0], ik4.z, st.lq_run);
+      st.lq_run = fmaf(d23[1], ik4.w, st.lq_run);
+    }
+    // publish P (16 B) and the reference for the partner wave
+    own_p = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    *reinterpret_cast<uint4*>(pbuf + (rg * 2 + W) * (64 * 16) + lane * 16) = own_p;
+    if (lh == 0) refbuf[(rg * 2 + W) * 32 + li] = st.m_w;
+  }
+
+  // ---- C. page i+1 landed for every wave; P/refs visible ----
+  if (more_in_flight)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- D. refill: rope/scale of page i+2 (slot of page i), latent of page i+3 (slot of page i-1) ----
+  if (src_rope != nullptr) {
+#pragma unroll
+    for (int k = 0; k < kRopePerWave; ++k) {
+      const int piece = wave * kRopePerWave + k;              // 8 token rows of 128 B each
+      const int T = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((T >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_rope + T * kDR + c * 8), (lds_ptr_t)(dma_rope + piece * 1024), 16,
+                                       0, 0);
+    }
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
+  }
+  if (src_nope != nullptr) {
+#pragma unroll
+    for (int k = 0; k < kNopePerWave; ++k) {
+      const int piece = wave * kNopePerWave + k;              // token rows 2*piece, 2*piece+1
+      const int T = piece * 2 + lh;
+      const int off = T * kDN + ((li ^ (T & 15)) << 4);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_nope + off), (lds_ptr_t)(dma_nope + piece * 1024), 16, 0, 0);
+    }
+  }
+
+  // ---- E. B operand of the PV MFMA: bytes 0..15 = wave 0's P of this lane, 16..31 = wave 1's; both references ----
+  const uint4 other_p = *reinterpret_cast<const uint4*>(pbuf + (rg * 2 + (1 - W)) * (64 * 16) + lane * 16);
+  const float m0 = refbuf[(rg * 2 + 0) * 32 + li];
+  const float m1 = refbuf[(rg * 2 + 1) * 32 + li];
+  const float mo_new = fmaxf(st.m_o, fmaxf(m0, m1));
+  if (__any(mo_new > st.m_o)) {
+    const float f = __builtin_amdgcn_exp2f(st.m_o - mo_new);   // exactly 1 where unchanged, 0 on the first page
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st.o[j][r] *= f;
+    st.m_o = mo_new;
+  }
+  int sb = 127 + (int)((lh ? m1 : m0) - st.m_o);
+  sb = sb < 0 ? 0 : sb;
+  const v8i pb = W == 0 ? make_v8i(own_p, other_p) : make_v8i(other_p, own_p);
+
+  // ---- F. O^T[256W + .., 32 rows] += V^T · P^T ----
+  const uint8_t* vp = rd_nope + W * 256;   // d half -> 16 chunks of 16 B further along every token row
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    v8i a;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint8_t* ap = vp + lc.vb[(jb & 3) | ((jb >> 2) << 2)] + (u & 1) * (16 * kDN) + (u >> 1) * (32 * kDN);
+      const v2i t2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)ap);
+      a[2 * u] = t2[0];
+      a[2 * u + 1] = t2[1];
+    }
+#ifdef FL_MLA_DEBUG
+    if (g_dbg != nullptr && tok0 == 0 && jb == 0) {
+      int* dd = g_dbg + (wave * 64 + lane) * 64;
+      for (int x = 0; x < 8; ++x) { dd[x] = pb[x]; dd[8 + x] = a[x]; }
+      dd[16] = sb; dd[17] = __float_as_int(m0); dd[18] = __float_as_int(m1); dd[19] = __float_as_int(st.m_o);
+      dd[20] = __float_as_int(st.m_w); dd[21] = __float_as_int(st.l_run);
+    }
+#endif
+    st.o[jb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, pb, st.o[jb], 0, 0, 0, kUnitScale, 0, sb);
+#ifdef FL_MLA_DEBUG
+    if (g_dbg != nullptr && tok0 == 0 && jb == 0) {
+      int* dd = g_dbg + (wave * 64 + lane) * 64;
+      for (int x = 0; x < 16; ++x) dd[32 + x] = __float_as_int(st.o[0][x]);
+    }
+#endif
+  }
+}
+
+// Read-only inputs are separate `const __restrict__` kernel arguments so that hipcc proves them invariant: wave-
+// uniform reads (page ids, lengths, scheduler rows) become s_load (lgkmcnt), never vector loads on the vmcnt queue.
+template <int NRG>
+__global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
     const Params p, const int32_t* __restrict__ g_block_table, const int32_t* __restrict__ g_seqlens,
     const int32_t* __restrict__ g_meta, const int32_t* __restrict__ g_num_splits,
     const uint8_t* __restrict__ g_k_nope, const uint16_t* __restrict__ g_k_rope, const float* __restrict__ g_k_scale,
     const uint8_t* __restrict__ g_q_nope, const uint16_t* __restrict__ g_q_rope, const float* __restrict__ g_q_scale) {
-  constexpr int NW = 2 * WH;                  // waves per workgroup
-  constexpr int kDmaPerWave = 64 / NW;        // 1-KiB pieces per wave per page pair
+  constexpr int NW = 2 * NRG;
   __shared__ __attribute__((aligned(16))) uint8_t smem[kLdsBytes];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wh = w % WH;
-  const int wt = w / WH;
-  const int li = lane & 31;   // MFMA row/col index held by this lane
-  const int lh = lane >> 5;   // k-half
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave % NRG;   // row group inside the workgroup
+  const int W = wave / NRG;    // token half (QK) / d half (PV)
+  LaneConst lc;
+  lc.lane = tid & 63;
+  lc.li = lc.lane & 31;
+  lc.lh = lc.lane >> 5;
+  {
+    const int li = lc.li, lh = lc.lh, lane = lc.lane;
+    // K operand: token T = 32W + li, 32 B at d = 64s + 32lh -> chunks c = 4s + 2lh + e, stored at chunk c ^ (T&15).
+    // bits of c: e->0, lh->1, s&3->2..3, s>>2->4 (not swizzled: +256 immediate).
+    const int kx = li & 15;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2)
+        lc.kb[e][k2] = li * kDN + (((((k2 ^ (kx >> 2)) << 2) | ((2 * lh + e) ^ (kx & 3))) << 4));
+    // rope operand: token T = 32W + li (W*32 rows is a multiple of 16 -> same swizzle), 16-B chunk 2s + lh stored
+    // at chunk (2s+lh) ^ ((T>>1)&7)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) lc.rb[s] = li * (kDR * 2) + ((((2 * s + lh) ^ ((li >> 1) & 7))) << 4);
+    // V^T: B-operand byte q of lane (row n, half lh) is P of token 32(q>>4) + 4lh + (q&3) + 8((q&15)>>2) (bytes 0..15
+    // = wave 0's 16 values of that lane, 16..31 = wave 1's).  tr8 read u covers q = 8u..8u+7: source lane
+    // s16 = lane&15 reads 8 B of token T = 4lh + tok_in8 + 16(u&1) + 32(u>>1) (immediates), chunk
+    // cj = 16W + (jb&3) + 8(jb>>2) + 4gi, half (s16&1)*8.  T&15 = 4lh + tok_in8 for every u.
+    const int s16 = lane & 15;
+    const int gi = (lane >> 4) & 1;
+    const int tj = s16 >> 1;
+    const int tok_in8 = (tj & 3) + ((tj >> 2) << 3);
+    const int vrow = 4 * lh + tok_in8;
+#pragma unroll
+    for (int k3 = 0; k3 < 8; ++k3) {
+      const int c4 = (k3 & 3) | (gi << 2) | (((k3 >> 2) & 1) << 3);
+      lc.vb[k3] = vrow * kDN + ((c4 ^ (vrow & 15)) << 4) + (s16 & 1) * 8;
+    }
+  }
+  const int lane = lc.lane, li = lc.li, lh = lc.lh;
 
   // ---- workgroup -> (part, row group); keep a request's row groups on one XCD (block b runs on XCD b%8) ----
-  int part, rg;
+  int part, rgrp;
   {
     const int id = blockIdx.x;
     if ((p.num_parts & 7) == 0) {
       const int xcd = id & 7, k = id >> 3;
-      rg = k % p.row_groups;
+      rgrp = k % p.row_groups;
       part = (k / p.row_groups) * 8 + xcd;
     } else {
-      rg = id % p.row_groups;
+      rgrp = id % p.row_groups;
       part = id / p.row_groups;
     }
   }
@@ -123,41 +378,10 @@ __global__ __launch_bounds__(128 * WH, 1) void mla_decode_fp8_kernel(
   const int end_tile = meta[3];
   int split_idx = meta[4];
 
-  const int row = rg * (32 * WH) + wh * 32 + li;   // query row of this lane
+  const int row = rgrp * (32 * NRG) + rg * 32 + li;   // query row of this lane
   const bool row_ok = row < p.rows;
 
-  uint8_t* sc_base = smem + kRingBytes + w * kScaleScratchPerWave;
-  float* sc_ks = reinterpret_cast<float*>(sc_base);
-  float* sc_lks = sc_ks + kPage;
-  float* sc_iks = sc_lks + kPage;
-
-  // ---- per-lane LDS offsets (within a slot): every lane-dependent XOR bit lives in 16 base registers, all
-  //      per-instruction variation is a compile-time immediate (ds offset field) ----
-  // K operand (QK): token T = 32*mb + li, 32 B at d = 64*s + 32*lh -> chunks c = 4s + 2lh + e (e=0,1), stored at
-  // chunk c ^ (T&15).  bits of c: e->0, lh->1, s&3->2..3, s>>2->4 (not swizzled: +256 immediate).
-  const int kx = li & 15;
-  int kb[2][4];
-#pragma unroll
-  for (int e = 0; e < 2; ++e)
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2)
-      kb[e][k2] = li * kDN + (((((k2 ^ (kx >> 2)) << 2) | ((2 * lh + e) ^ (kx & 3))) << 4));
-  // V^T operand (PV): ds_read_b64_tr_b8 source lane s16 = lane&15 reads 8 B of token T_u = 8192-B-immediate(u) +
-  // (4*lh + tok_in8) rows, d chunk cj = (jb>>2)*8 + (jb&3) + 4*gi (rows 16..31 of the M block <-> d + 64), half
-  // (s16&1)*8.  T_u & 15 = (4*lh + tok_in8) & 15 for every u.  bits of cj: jb&3->0..1, gi->2, (jb>>2)&1->3,
-  // jb>>3->4 (+256 immediate).
-  const int s16 = lane & 15;
-  const int gi = (lane >> 4) & 1;
-  const int tj = (s16 >> 1);
-  const int tok_in8 = (tj & 3) + ((tj >> 2) << 3);
-  const int vrow = 4 * lh + tok_in8;
-  const int vx = vrow & 15;
-  int vb[8];
-#pragma unroll
-  for (int k3 = 0; k3 < 8; ++k3) {
-    const int low4 = ((k3 & 3) ^ (vx & 3)) | ((gi ^ ((vx >> 2) & 1)) << 2) | ((((k3 >> 2) & 1) ^ (vx >> 3)) << 3);
-    vb[k3] = vrow * kDN + (low4 << 4) + (s16 & 1) * 8;
-  }
+  float* scratch = reinterpret_cast<float*>(smem + kOffScratch + wave * kScratchPerWave);
 
   for (; req < p.bs; ++req, tile_b = 0, split_idx = 0) {
     if (req > end_req || (req == end_req && end_tile == 0)) break;
@@ -165,11 +389,9 @@ __global__ __launch_bounds__(128 * WH, 1) void mla_decode_fp8_kernel(
     const int nt = L > 0 ? (L + kPage - 1) / kPage : 0;
     int tile_e = req < end_req ? nt : (end_tile < nt ? end_tile : nt);
     if (tile_e < tile_b) tile_e = tile_b;
-    const int ntile = tile_e - tile_b;
-    const int npairs = (ntile + 1) >> 1;
+    const int n = tile_e - tile_b;
     const int split_base = g_num_splits[req];
-    const int nsp = g_num_splits[req + 1] - split_base;
-    const bool is_split = nsp > 1;
+    const bool is_split = (g_num_splits[req + 1] - split_base) > 1;
 
     // ---- Q fragments (B operands), once per request ----
     const long long qrow = (long long)req * p.rows + row;
@@ -194,279 +416,178 @@ __global__ __launch_bounds__(128 * WH, 1) void mla_decode_fp8_kernel(
 #pragma unroll
       for (int s = 0; s < 4; ++s) qr[s] = as_bf8(make_uint4(0, 0, 0, 0));
     }
-    // causal limit of this row: query j sees keys [0, L - (s_q-1-j))
     int L_row = L;
-    if (p.causal) L_row = L - (p.s_q - 1 - row / p.h_q);
+    if (p.causal) L_row = L - (p.s_q - 1 - row / p.h_q);   // query j sees keys [0, L - (s_q-1-j))
     if (!row_ok) L_row = 0;
-    const int L_min = p.causal ? L - (p.s_q - 1) : L;   // smallest limit of any row (wave-uniform)
+    const int L_min = p.causal ? L - (p.s_q - 1) : L;
 
-    v16f o[16];
+    ReqState st;
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
-    float m_run = -1e30f;
-    float l_run = 0.f;
-    bool first_tile = true;
+      for (int r = 0; r < 16; ++r) st.o[j][r] = 0.f;
+    st.l_run = 0.f;
+    st.lq_run = 0.f;
+    st.m_w = kNegRef;
+    st.m_o = kNegRef;
 
-    // ---- DMA of one page pair into ring slots (pair&1)*2 + {0,1}: wave w moves kDmaPerWave 1-KiB pieces of ONE
-    //      page (all 64 token rows are read, the page is always fully allocated; rows past the sequence end are
-    //      zero-filled in LDS by the consumer) ----
-    const int dma_tp = (w * kDmaPerWave) >> 5;              // which page of the pair this wave fills
-    const int dma_row0 = ((w * kDmaPerWave) & 31) * 2 + lh;  // first token row this lane fills
-    const int dma_x = (lane & 31) << 4;
-    auto issue_pair = [&](int pair) {
-      const int tt = tile_b + 2 * pair + dma_tp;
-      if (tt < tile_e) {
-        int page = g_block_table[(long long)req * p.bt_stride + tt];
-        if (page < 0 || page >= p.num_pages) page = 0;
-        const uint8_t* pbase = g_k_nope + (long long)page * (kPage * kDN);
-        uint8_t* dst = smem + (((pair & 1) * 2 + dma_tp) * kSlotBytes) + ((w * kDmaPerWave) & 31) * 1024;
-#pragma unroll
-        for (int k = 0; k < kDmaPerWave; ++k) {
-          // token row T = dma_row0 + 2k; LDS chunk position lane&31 holds source chunk (lane&31) ^ (T&15)
-          const int T = dma_row0 + 2 * k;
-          const int off = T * kDN + (dma_x ^ ((T & 15) << 4));
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pbase + off), (lds_ptr_t)(dst + k * 1024), 16, 0, 0);
-        }
-      }
-    };
-
-    // rope + raw scale of one page straight to registers
-    uint4 rope[2][4];
-    float ks_raw = 1.f;
-    auto load_rope_scale = [&](int tt) {
-      int page = g_block_table[(long long)req * p.bt_stride + tt];
+    // page id -> global sources of one page (wave-uniform)
+    auto page_of = [&](int t) {
+      int page = g_block_table[(long long)req * p.bt_stride + tile_b + t];
       if (page < 0 || page >= p.num_pages) page = 0;
-      const uint16_t* rp = g_k_rope + ((long long)page * kPage + li) * kDR + lh * 8;
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) rope[mb][s] = *reinterpret_cast<const uint4*>(rp + mb * 32 * kDR + s * 16);
-      ks_raw = g_k_scale[(long long)page * kPage + lane];
+      return (long long)page;
     };
 
-    __syncthreads();   // previous request finished with the ring / merge area
-    if (npairs > 0) {
-      issue_pair(0);
-      if (tile_b + wt < tile_e) load_rope_scale(tile_b + wt);
+    // every wave finished with the LDS of the previous request (and the Q loads above are on the vmcnt queue: drain
+    // them before counted waits start)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- prologue: [r0 s0 n0] [r1 s1 n1] [n2] ----
+    {
+      constexpr int kNopePerWave = kDmaNopePerTile / NW;
+      constexpr int kRopePerWave = 8 / NW;
+      auto dma_rs = [&](int t) {
+        const long long pg = page_of(t);
+        const uint16_t* sr = g_k_rope + pg * (kPage * kDR);
+        const float* ss = g_k_scale + pg * kPage;
+        uint8_t* dr = smem + kOffRope + (t & 1) * kRopeBytes;
+        float* ds = reinterpret_cast<float*>(smem + kOffScale + (t & 1) * (kPage * 4));
+#pragma unroll
+        for (int k = 0; k < kRopePerWave; ++k) {
+          const int piece = wave * kRopePerWave + k;
+          const int T = piece * 8 + (lane >> 3);
+          const int c = (lane & 7) ^ ((T >> 1) & 7);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sr + T * kDR + c * 8), (lds_ptr_t)(dr + piece * 1024), 16, 0, 0);
+        }
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ss + lane), (lds_ptr_t)ds, 4, 0, 0);
+      };
+      auto dma_n = [&](int t) {
+        const uint8_t* sn = g_k_nope + page_of(t) * (kPage * kDN);
+        uint8_t* dn = smem + kOffRing + (t & 3) * kSlotBytes;
+#pragma unroll
+        for (int k = 0; k < kNopePerWave; ++k) {
+          const int piece = wave * kNopePerWave + k;
+          const int T = piece * 2 + lh;
+          const int off = T * kDN + ((li ^ (T & 15)) << 4);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sn + off), (lds_ptr_t)(dn + piece * 1024), 16, 0, 0);
+        }
+      };
+      if (n > 0) { dma_rs(0); dma_n(0); }
+      if (n > 1) { dma_rs(1); dma_n(1); }
+      if (n > 2) dma_n(2);
+      if (n > 2)
+        asm volatile("s_waitcnt vmcnt(19)" ::: "memory");   // leave [r1 s1 n1] [n2] = 11 + 8 in flight
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
 
-    for (int it = 0; it < npairs; ++it) {
-      __syncthreads();   // vmcnt(0): pair `it` landed (and rope/scale regs); slots of pair it+1 are free
-      if (it + 1 < npairs) issue_pair(it + 1);
-      const int tt = tile_b + 2 * it + wt;
-      if (tt < tile_e) {
-        uint8_t* slot = smem + (((it & 1) * 2 + wt) * kSlotBytes);
-        const int tok0 = tt * kPage;
-        if (tok0 + kPage > L) {
-          // last page of the sequence: rows past the end hold whatever the page held (possibly fp8 NaN patterns);
-          // P' is exactly 0 there but 0*NaN would poison the PV MFMA, so every consumer wave zeroes them itself.
-          const int nvalid = L - tok0;
-          for (int T = nvalid + (lane >> 5); T < kPage; T += 2)
-            *reinterpret_cast<uint4*>(slot + T * kDN + (lane & 31) * 16) = make_uint4(0, 0, 0, 0);
-        }
-        // ---- per-token scale preprocessing (lane t handles token t), wave-private scratch ----
-        {
-          float ks = ks_raw;
-          if (tok0 + lane >= L || !(ks > 0.f) || !(ks < 3.0e38f)) ks = 1.f;
-          sc_ks[lane] = ks;
-          sc_lks[lane] = __builtin_amdgcn_logf(ks);
-          sc_iks[lane] = __builtin_amdgcn_rcpf(ks);
-        }
-        // ---- S^T = K · Q^T ----
-        v16f acc[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb)
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(rope[mb][s]), qr[s], acc[mb], 0, 0, 0);
-        // next page's rope/scale (same registers; waited for only at the next ring barrier)
-        if (tt + 2 < tile_e) load_rope_scale(tt + 2);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb) {
-            const int imm = mb * (32 * kDN) + (s >> 2) * 256;
-            const uint4 a0 = *reinterpret_cast<const uint4*>(slot + kb[0][s & 3] + imm);
-            const uint4 a1 = *reinterpret_cast<const uint4*>(slot + kb[1][s & 3] + imm);
-            acc[mb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(a0, a1), qn[s], acc[mb], 0, 0, 0,
-                                                                      kUnitScale, 0, kUnitScale);
-          }
-        }
-        // ---- online softmax on y = s*log2e + log2(k_scale[t]) ----
-        const bool need_mask = (tok0 + kPage > L_min);
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int tb = mb * 32 + g * 8 + lh * 4;   // first of 4 consecutive tokens
-            const float4 ks4 = *reinterpret_cast<const float4*>(sc_ks + tb);
-            const float4 lk4 = *reinterpret_cast<const float4*>(sc_lks + tb);
-            const float ksv[4] = {ks4.x, ks4.y, ks4.z, ks4.w};
-            const float lkv[4] = {lk4.x, lk4.y, lk4.z, lk4.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float y = fmaf(acc[mb][g * 4 + e] * qs, ksv[e], lkv[e]);
-              if (need_mask && (tok0 + tb + e >= L_row)) y = -INFINITY;
-              if (!(y == y)) y = -INFINITY;   // NaN from garbage beyond the row's limit can only be masked data
-              acc[mb][g * 4 + e] = y;
-              tmax = fmaxf(tmax, y);
-            }
-          }
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        // defer-max (T13): keep the old reference unless some row's max grew by more than kRescaleThr; the PV of the
-        // previous page is complete, so O, l and the reference move together exactly once.
-        if (__any(tmax > m_run + kRescaleThr)) {
-          const float m_new = fmaxf(m_run, tmax);
-          if (!first_tile) {
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
-          }
-          m_run = m_new;
-        }
-        first_tile = false;
-        const float moff = kPShift - m_run;
-        v8i pb;
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int tb = mb * 32 + g * 8 + lh * 4;
-            const float4 ik4 = *reinterpret_cast<const float4*>(sc_iks + tb);
-            const float e0 = __builtin_amdgcn_exp2f(acc[mb][g * 4 + 0] + moff);
-            const float e1 = __builtin_amdgcn_exp2f(acc[mb][g * 4 + 1] + moff);
-            const float e2 = __builtin_amdgcn_exp2f(acc[mb][g * 4 + 2] + moff);
-            const float e3 = __builtin_amdgcn_exp2f(acc[mb][g * 4 + 3] + moff);
-            l_run = fmaf(e0, ik4.x, l_run);
-            l_run = fmaf(e1, ik4.y, l_run);
-            l_run = fmaf(e2, ik4.z, l_run);
-            l_run = fmaf(e3, ik4.w, l_run);
-            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(e0, e1, 0, false);
-            pk = __builtin_amdgcn_cvt_pk_fp8_f32(e2, e3, pk, true);
-            pb[mb * 4 + g] = pk;
-          }
-        }
-        // ---- O^T += V^T · P^T ----
-#pragma unroll
-        for (int jb = 0; jb < 16; ++jb) {
-          v8i a;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const uint8_t* ap = slot + vb[(jb & 3) | (((jb >> 2) & 1) << 2)] + u * (16 * kDN) + (jb >> 3) * 256;
-            const v2i t2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)ap);
-            a[2 * u] = t2[0];
-            a[2 * u + 1] = t2[1];
-          }
-          o[jb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, pb, o[jb], 0, 0, 0, kUnitScale, 0, kUnitScale);
+    for (int i = 0; i < n; ++i) {
+      const uint8_t* sn = nullptr;
+      const uint16_t* sr = nullptr;
+      const float* ss = nullptr;
+      if (i + 3 < n) sn = g_k_nope + page_of(i + 3) * (kPage * kDN);
+      if (i + 2 < n) {
+        const long long pg = page_of(i + 2);
+        sr = g_k_rope + pg * (kPage * kDR);
+        ss = g_k_scale + pg * kPage;
+      }
+      tile_body<NRG>(st, lc, qn, qr, qs, W, rg, wave,
+                     smem + kOffRing + (i & 3) * kSlotBytes, smem + kOffRope + (i & 1) * kRopeBytes,
+                     reinterpret_cast<const float*>(smem + kOffScale + (i & 1) * (kPage * 4)), scratch,
+                     smem + kOffPbuf + (i & 1) * kPbufPerParity,
+                     reinterpret_cast<float*>(smem + kOffRef + (i & 1) * kRefPerParity),
+                     smem + kOffRing + ((i + 3) & 3) * kSlotBytes, smem + kOffRope + (i & 1) * kRopeBytes,
+                     reinterpret_cast<float*>(smem + kOffScale + (i & 1) * (kPage * 4)), sn, sr, ss,
+                     (tile_b + i) * kPage, L, L_row, L_min, i + 2 < n);
+    }
+
+    // ---- per-request epilogue: merge the two normalisers of the row group, normalise, store this wave's d half ----
+    const float l_tot = st.l_run + __shfl_xor(st.l_run, 32);
+    const float lq_tot = st.lq_run + __shfl_xor(st.lq_run, 32);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // everyone is past the last page (P buffers free)
+    float* lm = reinterpret_cast<float*>(smem + kOffPbuf);   // [rg][W][3][32]
+    if (lh == 0) {
+      lm[((rg * 2 + W) * 3 + 0) * 32 + li] = l_tot;
+      lm[((rg * 2 + W) * 3 + 1) * 32 + li] = lq_tot;
+      lm[((rg * 2 + W) * 3 + 2) * 32 + li] = st.m_w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float mA = lm[((rg * 2 + 0) * 3 + 2) * 32 + li], mB = lm[((rg * 2 + 1) * 3 + 2) * 32 + li];
+    const float fA = __builtin_amdgcn_exp2f(mA - st.m_o), fB = __builtin_amdgcn_exp2f(mB - st.m_o);   // m_o >= mA, mB
+    const float l = lm[((rg * 2 + 0) * 3 + 0) * 32 + li] * fA + lm[((rg * 2 + 1) * 3 + 0) * 32 + li] * fB;
+    const float lq = lm[((rg * 2 + 0) * 3 + 1) * 32 + li] * fA + lm[((rg * 2 + 1) * 3 + 1) * 32 + li] * fB;
+    const float inv = lq > 0.f ? 1.f / lq : 0.f;
+    const float lse_nat = l > 0.f ? (__builtin_amdgcn_logf(l) + st.m_o - kPShift) * 0.6931471805599453f : -INFINITY;
+    // split-KV partials are normalised by lq, so they must also be COMBINED with lq-based weights (then the combine is
+    // exactly the unsplit sum O/lq); the exact LSE travels next to it for the reported lse.
+    const float lseq_nat = lq > 0.f ? (__builtin_amdgcn_logf(lq) + st.m_o - kPShift) * 0.6931471805599453f : -INFINITY;
+    if (row_ok) {
+      const int slot_idx = split_base + split_idx;
+      if (lh == 0 && W == 0) {
+        if (is_split) {
+          p.lse_accum[((long long)slot_idx * p.rows + row) * 2 + 0] = lseq_nat;
+          p.lse_accum[((long long)slot_idx * p.rows + row) * 2 + 1] = lse_nat;
+        } else {
+          const int j = row / p.h_q, h = row - j * p.h_q;
+          p.lse[((long long)req * p.h_q + h) * p.s_q + j] = lse_nat;
         }
       }
-    }
-
-    // ---- merge the two token-waves of each row group through LDS (aliases the ring) ----
-    l_run += __shfl_xor(l_run, 32);
-    __syncthreads();   // every wave is done reading ring slots
-    float* mg = reinterpret_cast<float*>(smem) + wh * (16 * 16 * 64);   // [jb][reg][lane] fp32, 64 KiB per row group
-    float* mg_ml = reinterpret_cast<float*>(smem + kRingBytes);        // scale scratch reused: [wh][2][64]
-    if (wt == 1) {
+      // C row i = e + 8g + 4*lh of tile jb  ->  d = 256W + (jb>>2)*128 + (jb&3)*16 + (i&15) + 64*(i>>4)
+      if (is_split) {
+        float* dbase = p.o_accum + ((long long)slot_idx * p.rows + row) * kDN + 256 * W;
 #pragma unroll
-      for (int jb = 0; jb < 16; ++jb)
+        for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mg[(jb * 16 + r) * 64 + lane] = o[jb][r];
-      mg_ml[(wh * 2 + 0) * 64 + lane] = m_run;
-      mg_ml[(wh * 2 + 1) * 64 + lane] = l_run;
-    }
-    __syncthreads();
-    if (wt == 0) {
-      const float m1 = mg_ml[(wh * 2 + 0) * 64 + lane];
-      const float l1 = mg_ml[(wh * 2 + 1) * 64 + lane];
-      const float m = fmaxf(m_run, m1);
-      const float a0 = __builtin_amdgcn_exp2f(m_run - m);
-      const float a1 = __builtin_amdgcn_exp2f(m1 - m);
-      const float l = l_run * a0 + l1 * a1;
-      const float inv = l > 0.f ? 1.f / l : 0.f;
-      const float w0 = a0 * inv, w1 = a1 * inv;
-      // natural-log LSE of the rows: log2(sum 2^x) = log2(l) + m - kPShift
-      const float lse_nat = l > 0.f ? (__builtin_amdgcn_logf(l) + m - kPShift) * 0.6931471805599453f : -INFINITY;
-      if (row_ok) {
-        const int slot_idx = split_base + split_idx;
-        if (lh == 0) {
-          if (is_split) {
-            p.lse_accum[(long long)slot_idx * p.rows + row] = lse_nat;
-          } else {
-            const int j = row / p.h_q, h = row - j * p.h_q;
-            p.lse[((long long)req * p.h_q + h) * p.s_q + j] = lse_nat;
+          for (int g = 0; g < 4; ++g) {
+            const int i0 = 8 * g + 4 * lh;
+            const int d0 = (jb >> 2) * 128 + (jb & 3) * 16 + (i0 & 15) + 64 * (i0 >> 4);
+            *reinterpret_cast<float4*>(dbase + d0) = make_float4(st.o[jb][g * 4 + 0] * inv, st.o[jb][g * 4 + 1] * inv,
+                                                                  st.o[jb][g * 4 + 2] * inv, st.o[jb][g * 4 + 3] * inv);
           }
-        }
-        if (is_split) {
-          float* dbase = p.o_accum + ((long long)slot_idx * p.rows + row) * kDN;
+      } else {
+        uint16_t* dbase = p.out + qrow * kDN + 256 * W;
 #pragma unroll
-          for (int jb = 0; jb < 16; ++jb) {
+        for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              float v[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int r = g * 4 + e;
-                v[e] = o[jb][r] * w0 + mg[(jb * 16 + r) * 64 + lane] * w1;
-              }
-              // C row i = e + 8g + 4*lh  ->  d = (jb>>2)*128 + (jb&3)*16 + (i&15) + 64*(i>>4)
-              const int i0 = 8 * g + 4 * lh;
-              const int d0 = (jb >> 2) * 128 + (jb & 3) * 16 + (i0 & 15) + 64 * (i0 >> 4);
-              *reinterpret_cast<float4*>(dbase + d0) = make_float4(v[0], v[1], v[2], v[3]);
-            }
+          for (int g = 0; g < 4; ++g) {
+            const int i0 = 8 * g + 4 * lh;
+            const int d0 = (jb >> 2) * 128 + (jb & 3) * 16 + (i0 & 15) + 64 * (i0 >> 4);
+            const uint32_t lo = (uint32_t)fl_f32_to_bf16(st.o[jb][g * 4 + 0] * inv) |
+                                ((uint32_t)fl_f32_to_bf16(st.o[jb][g * 4 + 1] * inv) << 16);
+            const uint32_t hi = (uint32_t)fl_f32_to_bf16(st.o[jb][g * 4 + 2] * inv) |
+                                ((uint32_t)fl_f32_to_bf16(st.o[jb][g * 4 + 3] * inv) << 16);
+            *reinterpret_cast<uint2*>(dbase + d0) = make_uint2(lo, hi);
           }
-        } else {
-          uint16_t* dbase = p.out + qrow * kDN;
-#pragma unroll
-          for (int jb = 0; jb < 16; ++jb) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              float v[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int r = g * 4 + e;
-                v[e] = o[jb][r] * w0 + mg[(jb * 16 + r) * 64 + lane] * w1;
-              }
-              const int i0 = 8 * g + 4 * lh;
-              const int d0 = (jb >> 2) * 128 + (jb & 3) * 16 + (i0 & 15) + 64 * (i0 >> 4);
-              const uint32_t lo = (uint32_t)fl_f32_to_bf16(v[0]) | ((uint32_t)fl_f32_to_bf16(v[1]) << 16);
-              const uint32_t hi = (uint32_t)fl_f32_to_bf16(v[2]) | ((uint32_t)fl_f32_to_bf16(v[3]) << 16);
-              *reinterpret_cast<uint2*>(dbase + d0) = make_uint2(lo, hi);
-            }
-          }
-        }
       }
     }
   }
 }
 
 // ---- split-KV combine: out[req,row,:] = sum_s w_s * o_accum[slot_s,row,:], w_s = softmax_s(lse_s) ----
-__global__ __launch_bounds__(256) void mla_combine_kernel(const Params p) {
+__global__ __launch_bounds__(256) void mla_combine_kernel(const Params p, const int32_t* __restrict__ g_num_splits) {
   const int lane = threadIdx.x & 63;
   const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gw >= (long long)p.bs * p.rows) return;
   const int req = (int)(gw / p.rows), row = (int)(gw % p.rows);
-  const int s0 = p.num_splits[req], ns = p.num_splits[req + 1] - s0;
+  const int s0 = g_num_splits[req], ns = g_num_splits[req + 1] - s0;
   if (ns <= 1) return;
-  float mx = -INFINITY;
-  for (int s = 0; s < ns; ++s) mx = fmaxf(mx, p.lse_accum[(long long)(s0 + s) * p.rows + row]);
-  float den = 0.f;
+  float mx = -INFINITY, mxx = -INFINITY;
+  for (int s = 0; s < ns; ++s) {
+    mx = fmaxf(mx, p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 0]);
+    mxx = fmaxf(mxx, p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 1]);
+  }
+  float den = 0.f, denx = 0.f;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int s = 0; s < ns; ++s) {
-    const float ls = p.lse_accum[(long long)(s0 + s) * p.rows + row];
+    const float ls = p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 0];
+    const float lx = p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 1];
     const float wgt = (mx == -INFINITY) ? 0.f : __expf(ls - mx);
     den += wgt;
+    denx += (mxx == -INFINITY) ? 0.f : __expf(lx - mxx);
     const float* src = p.o_accum + ((long long)(s0 + s) * p.rows + row) * kDN + lane * 8;
     const float4 a = *reinterpret_cast<const float4*>(src);
     const float4 b = *reinterpret_cast<const float4*>(src + 4);
@@ -481,7 +602,7 @@ __global__ __launch_bounds__(256) void mla_combine_kernel(const Params p) {
   *reinterpret_cast<uint4*>(p.out + ((long long)req * p.rows + row) * kDN + lane * 8) = make_uint4(o[0], o[1], o[2], o[3]);
   if (lane == 0) {
     const int j = row / p.h_q, h = row - j * p.h_q;
-    p.lse[((long long)req * p.h_q + h) * p.s_q + j] = den > 0.f ? mx + __logf(den) : -INFINITY;
+    p.lse[((long long)req * p.h_q + h) * p.s_q + j] = denx > 0.f ? mxx + __logf(denx) : -INFINITY;
   }
 }
 
@@ -501,22 +622,25 @@ int fl_mla_decode_fp8_per_token_impl(const FlMlaDecodeArgs* a, hipStream_t strea
   p.bs = a->bs; p.s_q = a->s_q; p.h_q = a->h_q; p.rows = a->s_q * a->h_q; p.causal = a->causal;
   p.num_parts = a->num_parts;
   p.scale_log2e = a->softmax_scale * kLog2e;
-  p.q_nope = (const uint8_t*)a->q_nope; p.q_rope = (const uint16_t*)a->q_rope; p.q_scale = a->q_scale;
-  p.k_nope = (const uint8_t*)a->k_nope; p.k_rope = (const uint16_t*)a->k_rope; p.k_scale = a->k_scale;
-  p.num_pages = a->num_pages; p.block_table = a->block_table; p.bt_stride = a->block_table_stride;
-  p.seqlens = a->cache_seqlens; p.meta = a->tile_scheduler_metadata; p.num_splits = a->num_splits;
+  p.num_pages = a->num_pages; p.bt_stride = a->block_table_stride;
   p.out = (uint16_t*)a->out; p.lse = a->lse; p.o_accum = a->o_accum; p.lse_accum = a->lse_accum;
-  // One shape for now: 2 row waves x 2 token waves (rows <= 32 leave the second row wave idle; the small-M
-  // "swap" kernel that splits tokens/d across waves instead is the next step).
-  const int wh = 2;
-  p.row_groups = (p.rows + 32 * wh - 1) / (32 * wh);
+  // One shape for now: 2 row groups x 2 halves (rows <= 32 leave the second row group idle; the small-M variant
+  // is the next step).
+  constexpr int NRG = 2;
+  p.row_groups = (p.rows + 32 * NRG - 1) / (32 * NRG);
   const unsigned grid = (unsigned)(p.num_parts * p.row_groups);
-  mla_decode_fp8_kernel<2><<<dim3(grid), dim3(256), 0, stream>>>(p, p.block_table, p.seqlens, p.meta, p.num_splits,
-                                                                  p.k_nope, p.k_rope, p.k_scale, p.q_nope, p.q_rope,
-                                                                  p.q_scale);
+  mla_decode_fp8_kernel<NRG><<<dim3(grid), dim3(128 * NRG), 0, stream>>>(
+      p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, a->num_splits, (const uint8_t*)a->k_nope,
+      (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
   FL_CHECK_LAUNCH("mla_decode_fp8_kernel");
   const long long waves = (long long)p.bs * p.rows;
-  mla_combine_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(p);
+  mla_combine_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(p, a->num_splits);
   FL_CHECK_LAUNCH("mla_combine_kernel");
   return FL_OK;
 }
+
+#ifdef FL_MLA_DEBUG
+extern "C" int fl_mla_debug_set_buffer(int* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &dev_ptr, sizeof(dev_ptr));
+}
+#endif

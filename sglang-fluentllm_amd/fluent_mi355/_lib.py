@@ -3,7 +3,8 @@ import os
 
 import torch
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfluent_mi355.so")
+LIB_PATH = os.environ.get("FLUENT_MI355_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                            "libfluent_mi355.so")
 
 _c_void_p = ctypes.c_void_p
 _i32p = ctypes.c_void_p

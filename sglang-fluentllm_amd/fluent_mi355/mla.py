@@ -131,7 +131,7 @@ def _common(args, q_like, block_table, cache_seqlens, tile_scheduler_metadata, n
     out = torch.empty((bs, s_q, h_q, 512), dtype=torch.bfloat16, device=dev)
     lse = torch.empty((bs, h_q, s_q), dtype=torch.float32, device=dev)
     o_accum = torch.empty((bs + num_parts, rows, 512), dtype=torch.float32, device=dev)
-    lse_accum = torch.empty((bs + num_parts, rows), dtype=torch.float32, device=dev)
+    lse_accum = torch.empty((bs + num_parts, rows, 2), dtype=torch.float32, device=dev)
     args.out, args.lse, args.o_accum, args.lse_accum = out.data_ptr(), lse.data_ptr(), o_accum.data_ptr(), lse_accum.data_ptr()
     return out, lse, (o_accum, lse_accum)
 
