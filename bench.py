@@ -78,8 +78,6 @@ def cpu_baseline(threads_cap=None):
     from oracle import mla_ref
 
     ncores = os.cpu_count() or 1
-    nthreads = min(ncores, threads_cap) if threads_cap else ncores
-    torch.set_num_threads(nthreads)
     g = torch.Generator().manual_seed(0)
     bs_s = 2
     npg = SEQ // 64
@@ -90,14 +88,24 @@ def cpu_baseline(threads_cap=None):
     q = torch.randn(bs_s, H, 576, generator=g).to(torch.bfloat16)
     seq = torch.full((bs_s,), SEQ, dtype=torch.int64)
     args = (q, kv, r2t, torch.arange(bs_s), seq, SCALE)
-    mla_ref.torch_native_decode(*args)  # warm-up
-    times = []
+    # the per-request SDPA is small: more threads than ~a socket's worth only adds synchronisation; take the best of a
+    # short sweep (fair to the CPU) and report the thread count actually used
+    best = None
     t_all = time.perf_counter()
-    while len(times) < 5 and (time.perf_counter() - t_all) < 25.0:
-        t0 = time.perf_counter()
-        mla_ref.torch_native_decode(*args)
-        times.append(time.perf_counter() - t0)
-    t = sorted(times)[len(times) // 2]
+    for nthreads in [c for c in (16, 32, 64, ncores) if c <= ncores]:
+        if threads_cap and nthreads > threads_cap:
+            continue
+        torch.set_num_threads(nthreads)
+        mla_ref.torch_native_decode(*args)  # warm-up
+        times = []
+        while len(times) < 3 and (time.perf_counter() - t_all) < 28.0:
+            t0 = time.perf_counter()
+            mla_ref.torch_native_decode(*args)
+            times.append(time.perf_counter() - t0)
+        if times and (best is None or sorted(times)[len(times) // 2] < best[0]):
+            best = (sorted(times)[len(times) // 2], nthreads, len(times))
+    t, nthreads, ntimes = best
+    times = [t] * ntimes
     per_req_layer = t / bs_s
     return {"value": 1.0 / (per_req_layer * LAYERS), "unit": "tokens/s", "cores": nthreads, "kind": "port",
             "sample": f"oracle.mla_ref.torch_native_decode (reference torch_native_backend.py:309-343 restated), bf16 KV, "
@@ -192,19 +200,43 @@ def main():
         for l in range(layers):
             k1(l)
         torch.cuda.synchronize()
-        reps = 3
+        # launch-overhead-free: the K1 launches of all layers are captured once and replayed; HIP events bracket the
+        # replays on the launch stream (torch's current stream)
+        reps = 5
+        k1_graph = None
+        if not a.no_graph:
+            s2 = torch.cuda.Stream()
+            s2.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s2):
+                k1(0)
+            torch.cuda.current_stream().wait_stream(s2)
+            k1_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(k1_graph):
+                for l in range(layers):
+                    k1(l)
+            k1_graph.replay()
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            for l in range(layers):
-                k1(l)
+            if k1_graph is not None:
+                k1_graph.replay()
+            else:
+                for l in range(layers):
+                    k1(l)
         e1.record()
         torch.cuda.synchronize()
         per_launch_s = e0.elapsed_time(e1) * 1e-3 / (reps * layers)
         alg = algorithmic_bytes(BS, SEQ, H, S_Q)
         achieved = alg / per_launch_s / 1e9
+        traffic = None   # HBM bytes per launch from the committed PMC passes of this kernel/workload (not re-measured here)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = round(json.load(f)["hbm_bytes_per_launch"])
+        except Exception:
+            pass
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "mla_decode_fp8_kernel(+mla_combine_kernel)", "us_per_launch": round(per_launch_s * 1e6, 2),
                 "algorithmic_bytes_per_launch": alg}
     cpu = None

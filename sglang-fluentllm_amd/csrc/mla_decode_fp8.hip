@@ -102,6 +102,8 @@ struct LaneConst {
   int kb[2][4];    // K operand: byte offset inside a slot, [e][s&3]; + (s>>2)*256 immediate; + W*16384
   int rb[4];       // rope operand: byte offset inside a rope slot, [s]
   int vb[8];       // V^T tr8 source: byte offset inside a slot, [(jb&3) | (jb>>2)<<2]; + u immediates
+  unsigned dn[16]; // latent DMA: byte offset of this lane's 16 B inside the page, per piece of this wave
+  unsigned dr[4];  // rope DMA: element offset inside the page's rope block, per piece of this wave
 };
 
 struct ReqState {
@@ -127,6 +129,25 @@ __device__ __forceinline__ void tile_body(
   constexpr int kNopePerWave = kDmaNopePerTile / NW;
   constexpr int kRopePerWave = 8 / NW;
   const int lane = lc.lane, li = lc.li, lh = lc.lh;
+#ifdef FL_EXP_NOCOMPUTE   // experiment: DMA pipeline only (streaming ceiling of this structure)
+  if (more_in_flight)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (src_rope != nullptr) {
+    for (int k = 0; k < kRopePerWave; ++k)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_rope + lc.dr[k]),
+                                       (lds_ptr_t)(dma_rope + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
+  }
+  if (src_nope != nullptr) {
+    for (int k = 0; k < kNopePerWave; ++k)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_nope + lc.dn[k]),
+                                       (lds_ptr_t)(dma_nope + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
+  }
+  return;
+#endif
 
   // ---- tail of the sequence: zero the rows past the end (every wave, all rows it may read) ----
   if (tok0 + kPage > L) {
@@ -148,10 +169,12 @@ __device__ __forceinline__ void tile_body(
     }
   }
 
-  // ---- A. S^T[32 tok x 32 rows] = K[32W + ..] · Q^T ----
+  // ---- A. S^T[32 tok x 32 rows] = K[32W + ..] · Q^T : all 20 operand reads in flight, then 12 back-to-back MFMAs ----
   v16f acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  float4 ks4[4], lk4[4], ik4[4];
   {
     const uint8_t* rp = rd_rope + W * (32 * kDR * 2);
     uint4 ra[4];
@@ -164,31 +187,69 @@ __device__ __forceinline__ void tile_body(
       ka[s][0] = *reinterpret_cast<const uint4*>(kp + lc.kb[0][s & 3] + (s >> 2) * 256);
       ka[s][1] = *reinterpret_cast<const uint4*>(kp + lc.kb[1][s & 3] + (s >> 2) * 256);
     }
+    // per-token scale triples of this lane's 16 tokens (written above by this wave): queued behind the operand
+    // reads, they land while the MFMAs run
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int tb = g * 8 + lh * 4;
+      ks4[g] = *reinterpret_cast<const float4*>(scratch + tb);
+      lk4[g] = *reinterpret_cast<const float4*>(scratch + 32 + tb);
+      ik4[g] = *reinterpret_cast<const float4*>(scratch + 64 + tb);
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ra[s]), qr[s], acc, 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < 8; ++s)
       acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc, 0, 0, 0,
                                                             kUnitScale, 0, kUnitScale);
+    __builtin_amdgcn_sched_group_barrier(0x100, 32, 0);   // DS reads: 20 operand + 12 scale
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);   // MFMA
   }
+  __builtin_amdgcn_sched_barrier(0);
+  // V^T operands of the first PV tiles: issued now, they land under the softmax
+  const uint8_t* vp = rd_nope + W * 256;   // d half -> 16 chunks of 16 B further along every token row
+  v8i va[8];
+  auto load_vt = [&](int jb) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint8_t* ap = vp + lc.vb[(jb & 3) | ((jb >> 2) << 2)] + (u & 1) * (16 * kDN) + (u >> 1) * (32 * kDN);
+      const v2i t2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)ap);
+      va[jb][2 * u] = t2[0];
+      va[jb][2 * u + 1] = t2[1];
+    }
+  };
+  load_vt(0);
+  load_vt(1);
+  load_vt(2);
+  __builtin_amdgcn_sched_barrier(0);
 
   // ---- B. local online softmax on y = s*log2e + log2(k_scale[t]); tokens of lane: 32W + 8g + 4lh + e ----
   const bool need_mask = (tok0 + kPage > L_min);
   float tmax = -INFINITY;
+  if (!need_mask) {
+    // every token of the page is valid for every row of the wave: no selects
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int tb = g * 8 + lh * 4;
-    const float4 ks4 = *reinterpret_cast<const float4*>(scratch + tb);
-    const float4 lk4 = *reinterpret_cast<const float4*>(scratch + 32 + tb);
-    const float ksv[4] = {ks4.x, ks4.y, ks4.z, ks4.w};
-    const float lkv[4] = {lk4.x, lk4.y, lk4.z, lk4.w};
+    for (int g = 0; g < 4; ++g) {
+      acc[g * 4 + 0] = fmaf(acc[g * 4 + 0] * qs, ks4[g].x, lk4[g].x);
+      acc[g * 4 + 1] = fmaf(acc[g * 4 + 1] * qs, ks4[g].y, lk4[g].y);
+      acc[g * 4 + 2] = fmaf(acc[g * 4 + 2] * qs, ks4[g].z, lk4[g].z);
+      acc[g * 4 + 3] = fmaf(acc[g * 4 + 3] * qs, ks4[g].w, lk4[g].w);
+      tmax = fmaxf(fmaxf(tmax, fmaxf(acc[g * 4 + 0], acc[g * 4 + 1])), fmaxf(acc[g * 4 + 2], acc[g * 4 + 3]));
+    }
+  } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float y = fmaf(acc[g * 4 + e] * qs, ksv[e], lkv[e]);
-      if (need_mask && (tok0 + 32 * W + tb + e >= L_row)) y = -INFINITY;
-      if (!(y == y)) y = -INFINITY;   // NaN can only come from garbage beyond the row's limit
-      acc[g * 4 + e] = y;
-      tmax = fmaxf(tmax, y);
+    for (int g = 0; g < 4; ++g) {
+      const int tb = g * 8 + lh * 4;
+      const float ksv[4] = {ks4[g].x, ks4[g].y, ks4[g].z, ks4[g].w};
+      const float lkv[4] = {lk4[g].x, lk4[g].y, lk4[g].z, lk4[g].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y = fmaf(acc[g * 4 + e] * qs, ksv[e], lkv[e]);
+        if (tok0 + 32 * W + tb + e >= L_row) y = -INFINITY;
+        if (!(y == y)) y = -INFINITY;   // NaN can only come from garbage beyond the row's limit
+        acc[g * 4 + e] = y;
+        tmax = fmaxf(tmax, y);
+      }
     }
   }
   tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
@@ -205,25 +266,23 @@ __device__ __forceinline__ void tile_body(
     int pk[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int tb = g * 8 + lh * 4;
-      const float4 ik4 = *reinterpret_cast<const float4*>(scratch + 64 + tb);
       const float e0 = __builtin_amdgcn_exp2f(acc[g * 4 + 0] + moff);
       const float e1 = __builtin_amdgcn_exp2f(acc[g * 4 + 1] + moff);
       const float e2 = __builtin_amdgcn_exp2f(acc[g * 4 + 2] + moff);
       const float e3 = __builtin_amdgcn_exp2f(acc[g * 4 + 3] + moff);
-      st.l_run = fmaf(e0, ik4.x, st.l_run);
-      st.l_run = fmaf(e1, ik4.y, st.l_run);
-      st.l_run = fmaf(e2, ik4.z, st.l_run);
-      st.l_run = fmaf(e3, ik4.w, st.l_run);
+      st.l_run = fmaf(e0, ik4[g].x, st.l_run);
+      st.l_run = fmaf(e1, ik4[g].y, st.l_run);
+      st.l_run = fmaf(e2, ik4[g].z, st.l_run);
+      st.l_run = fmaf(e3, ik4[g].w, st.l_run);
       int v = __builtin_amdgcn_cvt_pk_fp8_f32(e0, e1, 0, false);
       pk[g] = __builtin_amdgcn_cvt_pk_fp8_f32(e2, e3, v, true);
       // the ROUNDED weights normalise O (numerator and denominator use the same weights: they sum to exactly 1)
       const float2v d01 = __builtin_amdgcn_cvt_pk_f32_fp8(pk[g], false);
       const float2v d23 = __builtin_amdgcn_cvt_pk_f32_fp8(pk[g], true);
-      st.lq_run = fmaf(d01[0], ik4.x, st.lq_run);
-      st.lq_run = fmaf(d01[1], ik4.y, st.lq_run);
-      st.lq_run = fmaf(d23[0], ik4.z, st.lq_run);
-      st.lq_run = fmaf(d23[1], ik4.w, st.lq_run);
+      st.lq_run = fmaf(d01[0], ik4[g].x, st.lq_run);
+      st.lq_run = fmaf(d01[1], ik4[g].y, st.lq_run);
+      st.lq_run = fmaf(d23[0], ik4[g].z, st.lq_run);
+      st.lq_run = fmaf(d23[1], ik4[g].w, st.lq_run);
     }
     // publish P (16 B) and the reference for the partner wave
     own_p = make_uint4(pk[0], pk[1], pk[2], pk[3]);
@@ -232,33 +291,38 @@ __device__ __forceinline__ void tile_body(
   }
 
   // ---- C. page i+1 landed for every wave; P/refs visible ----
-  if (more_in_flight)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else
+  if (more_in_flight) {
+    if constexpr (NRG == 2)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // leave the latent pieces of page i+2 in flight
+    else
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   // ---- D. refill: rope/scale of page i+2 (slot of page i), latent of page i+3 (slot of page i-1) ----
+#ifdef FL_EXP_NODMA   // experiment: compute only
+  if (false) {
+#else
   if (src_rope != nullptr) {
+#endif
 #pragma unroll
-    for (int k = 0; k < kRopePerWave; ++k) {
-      const int piece = wave * kRopePerWave + k;              // 8 token rows of 128 B each
-      const int T = piece * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((T >> 1) & 7);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_rope + T * kDR + c * 8), (lds_ptr_t)(dma_rope + piece * 1024), 16,
-                                       0, 0);
-    }
+    for (int k = 0; k < kRopePerWave; ++k)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_rope + lc.dr[k]),
+                                       (lds_ptr_t)(dma_rope + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
   }
+#ifdef FL_EXP_NODMA
+  if (false) {
+#else
   if (src_nope != nullptr) {
+#endif
 #pragma unroll
-    for (int k = 0; k < kNopePerWave; ++k) {
-      const int piece = wave * kNopePerWave + k;              // token rows 2*piece, 2*piece+1
-      const int T = piece * 2 + lh;
-      const int off = T * kDN + ((li ^ (T & 15)) << 4);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_nope + off), (lds_ptr_t)(dma_nope + piece * 1024), 16, 0, 0);
-    }
+    for (int k = 0; k < kNopePerWave; ++k)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_nope + lc.dn[k]),
+                                       (lds_ptr_t)(dma_nope + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
   }
 
   // ---- E. B operand of the PV MFMA: bytes 0..15 = wave 0's P of this lane, 16..31 = wave 1's; both references ----
@@ -278,34 +342,18 @@ __device__ __forceinline__ void tile_body(
   sb = sb < 0 ? 0 : sb;
   const v8i pb = W == 0 ? make_v8i(own_p, other_p) : make_v8i(other_p, own_p);
 
-  // ---- F. O^T[256W + .., 32 rows] += V^T · P^T ----
-  const uint8_t* vp = rd_nope + W * 256;   // d half -> 16 chunks of 16 B further along every token row
+  // ---- F. O^T[256W + .., 32 rows] += V^T · P^T, operand reads three tiles ahead of their MFMA ----
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
-    v8i a;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint8_t* ap = vp + lc.vb[(jb & 3) | ((jb >> 2) << 2)] + (u & 1) * (16 * kDN) + (u >> 1) * (32 * kDN);
-      const v2i t2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)ap);
-      a[2 * u] = t2[0];
-      a[2 * u + 1] = t2[1];
-    }
-#ifdef FL_MLA_DEBUG
-    if (g_dbg != nullptr && tok0 == 0 && jb == 0) {
-      int* dd = g_dbg + (wave * 64 + lane) * 64;
-      for (int x = 0; x < 8; ++x) { dd[x] = pb[x]; dd[8 + x] = a[x]; }
-      dd[16] = sb; dd[17] = __float_as_int(m0); dd[18] = __float_as_int(m1); dd[19] = __float_as_int(st.m_o);
-      dd[20] = __float_as_int(st.m_w); dd[21] = __float_as_int(st.l_run);
-    }
-#endif
-    st.o[jb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, pb, st.o[jb], 0, 0, 0, kUnitScale, 0, sb);
-#ifdef FL_MLA_DEBUG
-    if (g_dbg != nullptr && tok0 == 0 && jb == 0) {
-      int* dd = g_dbg + (wave * 64 + lane) * 64;
-      for (int x = 0; x < 16; ++x) dd[32 + x] = __float_as_int(st.o[0][x]);
-    }
-#endif
+    if (jb + 3 < 8) load_vt(jb + 3);
+    st.o[jb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[jb], pb, st.o[jb], 0, 0, 0, kUnitScale, 0, sb);
   }
+#pragma unroll
+  for (int jb = 0; jb < 5; ++jb) {
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
 }
 
 // Read-only inputs are separate `const __restrict__` kernel arguments so that hipcc proves them invariant: wave-
@@ -354,6 +402,20 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
     for (int k3 = 0; k3 < 8; ++k3) {
       const int c4 = (k3 & 3) | (gi << 2) | (((k3 >> 2) & 1) << 3);
       lc.vb[k3] = vrow * kDN + ((c4 ^ (vrow & 15)) << 4) + (s16 & 1) * 8;
+    }
+  }
+  {
+    constexpr int kNopePerWave = kDmaNopePerTile / NW;
+    constexpr int kRopePerWave = 8 / NW;
+#pragma unroll
+    for (int k = 0; k < kNopePerWave; ++k) {
+      const int T = ((wave * kNopePerWave + k) * 2 + lc.lh);   // token row this lane fills
+      lc.dn[k] = (unsigned)(T * kDN + ((lc.li ^ (T & 15)) << 4));
+    }
+#pragma unroll
+    for (int k = 0; k < kRopePerWave; ++k) {
+      const int T = (wave * kRopePerWave + k) * 8 + (lc.lane >> 3);   // 8 token rows of 128 B per piece
+      lc.dr[k] = (unsigned)(T * kDR + (((lc.lane & 7) ^ ((T >> 1) & 7)) << 3));
     }
   }
   const int lane = lc.lane, li = lc.li, lh = lc.lh;
@@ -454,32 +516,30 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
         uint8_t* dr = smem + kOffRope + (t & 1) * kRopeBytes;
         float* ds = reinterpret_cast<float*>(smem + kOffScale + (t & 1) * (kPage * 4));
 #pragma unroll
-        for (int k = 0; k < kRopePerWave; ++k) {
-          const int piece = wave * kRopePerWave + k;
-          const int T = piece * 8 + (lane >> 3);
-          const int c = (lane & 7) ^ ((T >> 1) & 7);
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sr + T * kDR + c * 8), (lds_ptr_t)(dr + piece * 1024), 16, 0, 0);
-        }
+        for (int k = 0; k < kRopePerWave; ++k)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sr + lc.dr[k]), (lds_ptr_t)(dr + (wave * kRopePerWave + k) * 1024),
+                                           16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ss + lane), (lds_ptr_t)ds, 4, 0, 0);
       };
       auto dma_n = [&](int t) {
         const uint8_t* sn = g_k_nope + page_of(t) * (kPage * kDN);
         uint8_t* dn = smem + kOffRing + (t & 3) * kSlotBytes;
 #pragma unroll
-        for (int k = 0; k < kNopePerWave; ++k) {
-          const int piece = wave * kNopePerWave + k;
-          const int T = piece * 2 + lh;
-          const int off = T * kDN + ((li ^ (T & 15)) << 4);
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sn + off), (lds_ptr_t)(dn + piece * 1024), 16, 0, 0);
-        }
+        for (int k = 0; k < kNopePerWave; ++k)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sn + lc.dn[k]), (lds_ptr_t)(dn + (wave * kNopePerWave + k) * 1024),
+                                           16, 0, 0);
       };
       if (n > 0) { dma_rs(0); dma_n(0); }
       if (n > 1) { dma_rs(1); dma_n(1); }
       if (n > 2) dma_n(2);
-      if (n > 2)
-        asm volatile("s_waitcnt vmcnt(19)" ::: "memory");   // leave [r1 s1 n1] [n2] = 11 + 8 in flight
-      else
+      if (n > 2) {
+        if constexpr (NRG == 2)
+          asm volatile("s_waitcnt vmcnt(19)" ::: "memory");   // leave [r1 s1 n1] [n2] = (2+1+8) + 8 in flight
+        else
+          asm volatile("s_waitcnt vmcnt(37)" ::: "memory");   // (4+1+16) + 16
+      } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();
     }
 
@@ -624,14 +684,19 @@ int fl_mla_decode_fp8_per_token_impl(const FlMlaDecodeArgs* a, hipStream_t strea
   p.scale_log2e = a->softmax_scale * kLog2e;
   p.num_pages = a->num_pages; p.bt_stride = a->block_table_stride;
   p.out = (uint16_t*)a->out; p.lse = a->lse; p.o_accum = a->o_accum; p.lse_accum = a->lse_accum;
-  // One shape for now: 2 row groups x 2 halves (rows <= 32 leave the second row group idle; the small-M variant
-  // is the next step).
-  constexpr int NRG = 2;
-  p.row_groups = (p.rows + 32 * NRG - 1) / (32 * NRG);
+  // rows <= 32 (e.g. the TP8 shard, H=16): one row group per workgroup (2 waves); otherwise 2 row groups (4 waves).
+  // FL_MLA_ROWS_PER_WG (= 64) only sizes the scheduler's part count; both shapes give 1 row group for rows <= 32.
+  const int nrg = p.rows > 32 ? 2 : 1;
+  p.row_groups = (p.rows + 32 * nrg - 1) / (32 * nrg);
   const unsigned grid = (unsigned)(p.num_parts * p.row_groups);
-  mla_decode_fp8_kernel<NRG><<<dim3(grid), dim3(128 * NRG), 0, stream>>>(
-      p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, a->num_splits, (const uint8_t*)a->k_nope,
-      (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
+  if (nrg == 2)
+    mla_decode_fp8_kernel<2><<<dim3(grid), dim3(256), 0, stream>>>(
+        p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, a->num_splits, (const uint8_t*)a->k_nope,
+        (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
+  else
+    mla_decode_fp8_kernel<1><<<dim3(grid), dim3(128), 0, stream>>>(
+        p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, a->num_splits, (const uint8_t*)a->k_nope,
+        (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
   FL_CHECK_LAUNCH("mla_decode_fp8_kernel");
   const long long waves = (long long)p.bs * p.rows;
   mla_combine_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(p, a->num_splits);

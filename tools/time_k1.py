@@ -1,0 +1,29 @@
+"""Timing helper (GPU box): K1 only on the bench workload; FLUENT_MI355_LIB selects an experimental build."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sglang-fluentllm_amd"))
+import torch, bench
+import flash_mla_fp8 as fm
+layers = 8
+H = int(sys.argv[1]) if len(sys.argv) > 1 else bench.H
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else bench.BS
+seq = int(sys.argv[3]) if len(sys.argv) > 3 else bench.SEQ
+dev = torch.device("cuda:0")
+wl = bench.build_workload(dev, layers, bs, seq, H, seed=1)
+meta, ns = fm.get_mla_metadata(wl["seqlens"], H, 1)
+qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
+pages = wl["pages"]
+def k1(l):
+    k_lora, k_scale, k_rope = wl["caches"][l]
+    fm.flash_mla_ckv_fp8_per_token(qn, qr, k_lora.view(pages, 64, 1, 512), k_rope.view(pages, 64, 1, 64), qs,
+                                   k_scale.view(pages, 64, 1, 1), wl["block_table"], wl["seqlens"], 512, meta, ns, bench.SCALE, True)
+for l in range(layers): k1(l)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    for l in range(layers): k1(l)
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / (5 * layers)
+alg = bench.algorithmic_bytes(bs, seq, H, 1)
+print(f"{os.environ.get('FLUENT_MI355_LIB','default').split('/')[-1]} H={H} bs={bs} seq={seq}: {us:.1f} us/launch  {alg/us/1e3:.0f} GB/s ({alg/us/1e3/8000*100:.1f}% of 8 TB/s)")
