@@ -91,6 +91,46 @@ typedef struct FlMlaDecodeArgs {
 
 int fl_mla_decode(const FlMlaDecodeArgs* args, fl_stream_t stream);
 
+/* ---- G1-G4: deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_{offset,contiguous,masked} / gemm_fp8_fp8_bf16_nt
+ * (srt/layers/moe/gemms/fp8/fire.py:18 -> moe/executors/fp8_eps_executor.py:56,78;
+ *  moe/executors/deep_ep_executor.py:583-586,607-613,655-662,681-688; dense/gemms/fp8/deep_geem.py:55) ---- */
+#define FL_GEMM_OFFSET 0      /* rows [meta[e], meta[e+1]) use group e; meta = exclusive_sum i32 [E+1] */
+#define FL_GEMM_CONTIGUOUS 1  /* row i uses group meta[i] (<0 = skip), groups 128-row aligned; meta = m_indices i32 [M] */
+#define FL_GEMM_MASKED 2      /* A [G, rows_per_group, K], first meta[g] rows of group g valid; meta = masked_m i32 [G] */
+#define FL_GEMM_DENSE 3       /* one group, meta unused */
+typedef struct FlGemmArgs {
+  int32_t mode;
+  int32_t num_groups;         /* E (1 for dense) */
+  int64_t M;                  /* total rows of A/out (masked: G*rows_per_group) */
+  int32_t N, K;               /* W is [E, N, K] fp8, K % 128 == 0 */
+  int64_t rows_per_group;     /* masked only */
+  int64_t expected_m;         /* hint for the token-tile height (0 = derive) */
+  const void* A;              /* fp8 [M, K] row-major */
+  const float* As;            /* f32 scales of A, element (m, kb) at m*as_stride_m + kb*as_stride_k */
+  int64_t as_stride_m, as_stride_k;
+  int64_t as_stride_g;        /* masked only: stride between groups of As */
+  const void* W;              /* fp8 [E, N, K] */
+  const float* Ws;            /* f32 [E, ceil(N/128), K/128] */
+  void* out;                  /* bf16 [M, N] */
+  const int32_t* group_meta;
+} FlGemmArgs;
+int fl_grouped_gemm_fp8(const FlGemmArgs* args, fl_stream_t stream);
+int fl_gemm_set_num_cus(int n);   /* deep_gemm.set_num_sms (srt/tbo/tbo_executor.py:129-134) */
+int fl_gemm_get_num_cus(void);
+
+/* ---- Q1/Q2: 1x128 per-token-group FP8 quantisation (flashinfer.quantization.quant_1x128,
+ * moe/executors/fp8_eps_executor.py:53-55,75-77; flashinfer.sgl_per_token_group_quant_fp8,
+ * dense/gemms/fp8/fp8_kernel.py:457-460).  s = max(amax, eps)/448 (fp32), q = x/s -> e4m3 (RNE).
+ * x bf16 [M, K]; scale (m, kb) written at m*s_stride_m + kb*s_stride_k. ---- */
+int fl_quant_1x128(const void* x, int64_t M, int K, float eps, void* x_q, float* x_s, int64_t s_stride_m,
+                   int64_t s_stride_k, fl_stream_t stream);
+
+/* ---- A1: silu(x[:, :I]) * x[:, I:] (eps.executor.silu, fp8_eps_executor.py:62; flashinfer.silu_and_mul), bf16;
+ * with q_out != NULL also emits the 1x128 quantisation of the result
+ * (flashinfer.activation.silu_and_mul_fuse_block_quant, deep_ep_executor.py:676, activation.py:73). ---- */
+int fl_silu_and_mul(const void* x, int64_t M, int I, void* out_bf16, void* q_out, float* s_out, int64_t s_stride_m,
+                    int64_t s_stride_k, fl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,318 @@
+// G1-G4 — FP8 (e4m3) block-scaled (1x128 activations, 128x128 weights) grouped GEMM, bf16 out, gfx950 only.
+//
+// Replaces deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_{offset,contiguous,masked} and gemm_fp8_fp8_bf16_nt
+// (call sites /root/reference/python/sglang/srt/layers/moe/gemms/fp8/fire.py:18 via
+//  moe/executors/fp8_eps_executor.py:56,78; moe/executors/deep_ep_executor.py:583-586,607-613,655-662,681-688;
+//  dense/gemms/fp8/deep_geem.py:55).  Math = python/sglang/test/test_block_fp8.py:89-141:
+//     out[m, n] = sum_kb ( sum_{k in kb} A[m,k] * W[e,n,k] ) * As[m,kb] * Ws[e, n/128, kb]     (fp32 accumulate)
+//
+// MI355X mapping ("SwapAB"): the WEIGHT rows sit on the MFMA M side and the token rows on the N side
+// (D^T[n, m] = W_tile · A_tile^T on v_mfma_scale_f32_32x32x64_f8f6f4, unit E8M0 scales, 2 per 128-wide k block), so
+//   * a lane owns ONE token row (lane&31): its per-(token, k-block) scale As[m,kb] * Ws[e,nb,kb] is a single
+//     per-lane factor applied to the whole 32x32 partial tile with 16 FMAs — no per-row scale shuffles;
+//   * the decode regime (a handful of rows per expert) wastes MFMA columns, not weight bandwidth: every workgroup
+//     streams a [128 n x K] weight panel exactly once.
+// One workgroup = 4 waves = 128 weight rows x (32*MT) token rows; wave w owns weight rows 32w..32w+31 and all MT
+// token tiles.  HBM -> LDS by global_load_lds into a 4-stage ring of [W 16 KiB | A MT*4 KiB | As] k-block stages
+// (XOR-swizzled on the source address for conflict-free ds_read_b128), counted vmcnt waits + one raw s_barrier per
+// k block.  Tiles of experts with no rows are never scheduled; the grid is an upper bound, surplus blocks exit.
+//
+// Algorithmic bytes / flops per MoE layer: SURVEY.md §8(d) (weights 44.04 MB per expert hit, 88.08 MFLOP per row).
+#include "fl_common.h"
+
+namespace {
+
+constexpr int BN = 128;            // weight rows per workgroup (= one 128-row scale block)
+constexpr int BK = 128;            // k block (bytes per row per stage)
+constexpr int kStages = 4;
+constexpr int kWBytes = BN * BK;   // 16 KiB
+constexpr int kUnit = 0x7F;
+
+enum Mode { kOffset = 0, kContiguous = 1, kMasked = 2, kDense = 3 };
+
+struct GemmParams {
+  int mode, E, M, N, K;
+  int n_tiles, m_tiles_upper;
+  long long as_stride_m, as_stride_k, as_stride_g;   // element strides of As (g: masked mode only)
+  long long rows_per_group;             // masked mode: padded rows per group
+  uint16_t* out;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ v8i mk8(uint4 a, uint4 b) {
+  v8i r;
+  r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+  return r;
+}
+
+template <int MT>
+struct Smem {
+  static constexpr int kABytes = MT * 32 * BK;
+  static constexpr int kAsFloats = MT * 32 < 64 ? 64 : MT * 32;
+  static constexpr int kStageBytes = kWBytes + kABytes + kAsFloats * 4;
+  static constexpr int kTotal = kStages * kStageBytes;
+};
+
+// One k block for one wave: wait for its stage, refill the stage freed one barrier ago, compute.  The LDS regions are
+// distinct __restrict__ parameters of ONE inlined function so that hipcc's waitcnt pass does not assume every ds_read
+// may alias the in-flight LDS-DMA and drain it with vmcnt(0) (see mla_decode_fp8.hip).
+template <int MT>
+__device__ __forceinline__ void kblock_body(v16f (&acc)[MT], const uint8_t* __restrict__ rd_w,
+                                            const uint8_t* __restrict__ rd_a, const float* __restrict__ rd_as,
+                                            uint8_t* __restrict__ dma_w, uint8_t* __restrict__ dma_a,
+                                            float* __restrict__ dma_as, const uint8_t* const (&src_w)[4],
+                                            const uint8_t* const (&src_a)[MT],
+                                            const float* const (&src_as)[Smem<MT>::kAsFloats / 64], const long long k_off,
+                                            const long long as_off, const bool issue, const bool more_in_flight,
+                                            const float ws, const int (&rb)[4], const int wave, const int li) {
+  constexpr int kAsPieces = Smem<MT>::kAsFloats / 64;
+  // ---- stage kb landed for every wave; stages kb+1, kb+2 (issued later) may stay in flight ----
+  if (more_in_flight) {
+    if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");        // 2 stages x (4 + 1 + 1) pieces
+    else if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");   // 2 x (4 + 2 + 1)
+    else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");                          // 2 x (4 + 4 + 2)
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  // ---- refill the stage every wave finished with before this barrier ----
+  if (issue) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)   // W: 16 pieces of 8 rows x 128 B; this wave fills pieces 4*wave + k
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_w[k] + k_off), (lds_ptr_t)(dma_w + (wave * 4 + k) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < MT; ++k)  // A: 4*MT pieces; this wave fills pieces wave*MT + k
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_a[k] + k_off), (lds_ptr_t)(dma_a + (wave * MT + k) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < kAsPieces; ++k)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_as[k] + as_off), (lds_ptr_t)(dma_as + k * 64), 4, 0, 0);
+  }
+  // ---- operands: 4 + 4*MT ds_read_b128 in flight, then the MFMAs ----
+  const uint8_t* wp = rd_w + wave * (32 * BK);
+  uint4 wa[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) wa[s] = *reinterpret_cast<const uint4*>(wp + rb[s]);
+  uint4 ab[MT][4];
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ab[j][s] = *reinterpret_cast<const uint4*>(rd_a + j * (32 * BK) + rb[s]);
+  float sc[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) sc[j] = rd_as[j * 32 + li] * ws;
+  const v8i a0 = mk8(wa[0], wa[1]), a1 = mk8(wa[2], wa[3]);
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    v16f part;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[r] = 0.f;
+    part = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, mk8(ab[j][0], ab[j][1]), part, 0, 0, 0, kUnit, 0, kUnit);
+    part = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, mk8(ab[j][2], ab[j][3]), part, 0, 0, 0, kUnit, 0, kUnit);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = fmaf(part[r], sc[j], acc[j][r]);
+  }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 1) void grouped_gemm_fp8_kernel(const GemmParams p, const uint8_t* __restrict__ gA,
+                                                                   const float* __restrict__ gAs,
+                                                                   const uint8_t* __restrict__ gW,
+                                                                   const float* __restrict__ gWs,
+                                                                   const int32_t* __restrict__ gmeta) {
+  constexpr int BM = 32 * MT;
+  __shared__ __attribute__((aligned(16))) uint8_t smem[Smem<MT>::kTotal];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+
+  // ---- tile -> (expert, token range, weight tile) ----
+  const int nt = blockIdx.x % p.n_tiles;
+  const int mt = blockIdx.x / p.n_tiles;
+  int e = 0;
+  long long row0 = 0;     // first row of the tile in A / out
+  long long row_end = 0;  // one past the last valid row
+  if (p.mode == kOffset) {
+    int t = mt, found = 0;
+    for (int g = 0; g < p.E; ++g) {
+      const int lo = gmeta[g], hi = gmeta[g + 1];
+      const int tiles = (hi - lo + BM - 1) / BM;
+      if (t < tiles) { e = g; row0 = lo + (long long)t * BM; row_end = hi; found = 1; break; }
+      t -= tiles;
+    }
+    if (!found) return;
+  } else if (p.mode == kContiguous) {
+    row0 = (long long)mt * BM;
+    if (row0 >= p.M) return;
+    e = gmeta[row0];
+    if (e < 0 || e >= p.E) return;
+    row_end = row0 + BM < p.M ? row0 + BM : p.M;
+  } else if (p.mode == kMasked) {
+    const int tpg = (int)((p.rows_per_group + BM - 1) / BM);
+    e = mt / tpg;
+    if (e >= p.E) return;
+    const int mm = gmeta[e];
+    const long long r = (long long)(mt % tpg) * BM;
+    if (r >= mm) return;
+    row0 = (long long)e * p.rows_per_group + r;
+    row_end = (long long)e * p.rows_per_group + mm;
+  } else {
+    row0 = (long long)mt * BM;
+    if (row0 >= p.M) return;
+    row_end = p.M;
+  }
+  const int n0 = nt * BN;
+  const int KB = p.K / BK;
+
+  // ---- per-lane DMA sources (k-invariant parts) ----
+  // W piece (wave*4 + k): rows 8*(wave*4+k) + (lane>>3); LDS chunk position lane&7 holds source chunk (lane&7)^((r>>1)&7)
+  const int wr = (wave * 4) * 8 + (lane >> 3);
+  // pre-clamped row pointers for the 4 W pieces of this wave (rows beyond N are clamped: results discarded)
+  const uint8_t* wsrc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = wr + 8 * k;
+    int n = n0 + r;
+    n = n < p.N ? n : p.N - 1;
+    wsrc[k] = gW + ((long long)e * p.N + n) * p.K + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+  }
+  const uint8_t* asrc[MT];
+#pragma unroll
+  for (int k = 0; k < MT; ++k) {
+    const int r = (wave * MT + k) * 8 + (lane >> 3);   // row inside the token tile
+    long long m = row0 + r;
+    m = m < row_end ? m : row_end - 1;
+    asrc[k] = gA + m * p.K + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+  }
+  constexpr int kAsPieces = Smem<MT>::kAsFloats / 64;
+  const float* assrc[kAsPieces];
+#pragma unroll
+  for (int k = 0; k < kAsPieces; ++k) {
+    long long m = row0 + k * 64 + lane;
+    m = m < row_end ? m : row_end - 1;
+    // masked mode: scales are indexed [group, row in group, kb]
+    assrc[k] = p.mode == kMasked ? gAs + (long long)e * p.as_stride_g + (m - (long long)e * p.rows_per_group) * p.as_stride_m
+                                 : gAs + m * p.as_stride_m;
+  }
+  // operand read offsets inside a 32-row x 128 B sub-tile: row li, 16-B chunk c = 4*s2 + 2*lh + e2 (s = 2*s2 + e2)
+  int rb[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int c = 4 * (s >> 1) + 2 * lh + (s & 1);
+    rb[s] = li * BK + ((c ^ ((li >> 1) & 7)) << 4);
+  }
+
+  v16f acc[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  auto stage_w = [&](int st) { return smem + st * Smem<MT>::kStageBytes; };
+  auto stage_a = [&](int st) { return smem + st * Smem<MT>::kStageBytes + kWBytes; };
+  auto stage_as = [&](int st) {
+    return reinterpret_cast<float*>(smem + st * Smem<MT>::kStageBytes + kWBytes + Smem<MT>::kABytes);
+  };
+  auto issue_stage = [&](int kb) {
+    const int st = kb % kStages;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc[k] + (long long)kb * BK), (lds_ptr_t)(stage_w(st) + (wave * 4 + k) * 1024),
+                                       16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < MT; ++k)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[k] + (long long)kb * BK),
+                                       (lds_ptr_t)(stage_a(st) + (wave * MT + k) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < kAsPieces; ++k)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(assrc[k] + (long long)kb * p.as_stride_k),
+                                       (lds_ptr_t)(stage_as(st) + k * 64), 4, 0, 0);
+  };
+
+  // ---- prologue: stages 0 .. kStages-2 ----
+#pragma unroll
+  for (int s = 0; s < kStages - 1; ++s)
+    if (s < KB) issue_stage(s);
+
+  const float* wsrow = gWs + ((long long)e * ((p.N + BN - 1) / BN) + nt) * KB;
+  for (int kb = 0; kb < KB; ++kb) {
+    const int st = kb % kStages;
+    const int nst = (kb + kStages - 1) % kStages;
+    kblock_body<MT>(acc, stage_w(st), stage_a(st), stage_as(st), stage_w(nst), stage_a(nst), stage_as(nst), wsrc, asrc,
+                    assrc, (long long)(kb + kStages - 1) * BK, (long long)(kb + kStages - 1) * p.as_stride_k,
+                    kb + kStages - 1 < KB, kb + 2 < KB, wsrow[kb], rb, wave, li);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: D^T[n, m] -> out[m, n] bf16; lane (m = li, half lh) holds n = 32*wave + 8g + 4lh + (0..3) ----
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const long long m = row0 + j * 32 + li;
+    if (m < row_end) {
+      uint16_t* orow = p.out + m * p.N;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wave * 32 + 8 * g + 4 * lh;
+        if (n + 3 < p.N) {
+          const uint32_t lo = (uint32_t)fl_f32_to_bf16(acc[j][4 * g + 0]) | ((uint32_t)fl_f32_to_bf16(acc[j][4 * g + 1]) << 16);
+          const uint32_t hi = (uint32_t)fl_f32_to_bf16(acc[j][4 * g + 2]) | ((uint32_t)fl_f32_to_bf16(acc[j][4 * g + 3]) << 16);
+          *reinterpret_cast<uint2*>(orow + n) = make_uint2(lo, hi);
+        } else {
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+            if (n + x < p.N) orow[n + x] = fl_f32_to_bf16(acc[j][4 * g + x]);
+        }
+      }
+    }
+  }
+}
+
+int g_num_cus_limit = 0;   // deep_gemm.set_num_sms (tbo/tbo_executor.py:129-134): advisory on this path
+
+}  // namespace
+
+extern "C" int fl_gemm_set_num_cus(int n) { g_num_cus_limit = n; return FL_OK; }
+extern "C" int fl_gemm_get_num_cus(void) { return g_num_cus_limit; }
+
+extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
+  FL_CHECK_ARG(a != nullptr, "fl_grouped_gemm_fp8: null args");
+  FL_CHECK_ARG(a->mode >= 0 && a->mode <= 3, "fl_grouped_gemm_fp8: bad mode %d", a->mode);
+  if (a->M == 0) return FL_OK;   // nothing routed to this rank (empty tensors have null pointers)
+  FL_CHECK_ARG(a->A && a->As && a->W && a->Ws && a->out, "fl_grouped_gemm_fp8: null tensor pointer");
+  FL_CHECK_ARG(a->mode == kDense || a->group_meta, "fl_grouped_gemm_fp8: null group metadata");
+  FL_CHECK_ARG(a->K > 0 && a->K % BK == 0, "fl_grouped_gemm_fp8: K=%d must be a multiple of 128", a->K);
+  FL_CHECK_ARG(a->N > 0 && a->N % 4 == 0, "fl_grouped_gemm_fp8: N=%d must be a multiple of 4", a->N);
+  FL_CHECK_ARG(a->num_groups >= 1 && a->M >= 0, "fl_grouped_gemm_fp8: bad sizes");
+  if (a->M == 0) return FL_OK;
+  GemmParams p;
+  p.mode = a->mode; p.E = a->num_groups; p.M = (int)a->M; p.N = a->N; p.K = a->K;
+  p.as_stride_m = a->as_stride_m; p.as_stride_k = a->as_stride_k; p.as_stride_g = a->as_stride_g;
+  p.rows_per_group = a->rows_per_group;
+  p.out = (uint16_t*)a->out;
+  p.n_tiles = (a->N + BN - 1) / BN;
+  // token-tile height from the expected rows per group (host-side hint only: correctness does not depend on it)
+  long long avg = a->expected_m > 0 ? a->expected_m : (a->mode == kMasked ? a->rows_per_group : a->M / a->num_groups);
+  if (a->mode == kDense) avg = a->M;
+  int mt = avg <= 32 ? 1 : (avg <= 64 ? 2 : 4);
+  if (a->mode == kContiguous) mt = 4;   // groups are 128-row aligned by contract (deep_ep_executor.py:282,290)
+  const int bm = 32 * mt;
+  long long m_tiles;
+  if (a->mode == kOffset) m_tiles = (a->M + bm - 1) / bm + a->num_groups;
+  else if (a->mode == kMasked) m_tiles = (long long)a->num_groups * ((a->rows_per_group + bm - 1) / bm);
+  else m_tiles = (a->M + bm - 1) / bm;
+  p.m_tiles_upper = (int)m_tiles;
+  const long long blocks = m_tiles * p.n_tiles;
+  FL_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fl_grouped_gemm_fp8: grid too large");
+  const dim3 grid((unsigned)blocks), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (mt == 1)
+    grouped_gemm_fp8_kernel<1><<<grid, block, 0, s>>>(p, (const uint8_t*)a->A, a->As, (const uint8_t*)a->W, a->Ws, a->group_meta);
+  else if (mt == 2)
+    grouped_gemm_fp8_kernel<2><<<grid, block, 0, s>>>(p, (const uint8_t*)a->A, a->As, (const uint8_t*)a->W, a->Ws, a->group_meta);
+  else
+    grouped_gemm_fp8_kernel<4><<<grid, block, 0, s>>>(p, (const uint8_t*)a->A, a->As, (const uint8_t*)a->W, a->Ws, a->group_meta);
+  FL_CHECK_LAUNCH("grouped_gemm_fp8_kernel");
+  return FL_OK;
+}

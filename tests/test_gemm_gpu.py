@@ -1,0 +1,214 @@
+"""GPU parity tests of the FP8 block-scaled grouped GEMM / quant / activation path (pytest -m gpu), through the
+drop-in modules (`deep_gemm`, `flashinfer`, `eps`) -> ctypes -> C-ABI -> HIP kernels, against the oracle
+(oracle/gemm_ref.py = python/sglang/test/test_block_fp8.py restated) and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import bf16_from_u16, fp8_from_u8, load_golden, rel_mae
+from oracle import gemm_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def fp8_weights(g, *shape):
+    return ((torch.rand(*shape, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(torch.float8_e4m3fn)
+
+
+# ------------------------------------------------------------------ Q1/Q2 + A1: bit-exact byte work
+def test_quant_1x128_bit_exact_vs_reference_golden():
+    import flashinfer
+
+    g = load_golden("gemm_block_fp8.npz")
+    x = bf16_from_u16(g["quant_x"]).to(DEV)
+    M, K = x.shape
+    xq = torch.empty(M, K, dtype=torch.float8_e4m3fn, device=DEV)
+    xs = torch.empty(M, K // 128, dtype=torch.float32, device=DEV)
+    flashinfer.sgl_per_token_group_quant_fp8(x, xq, xs, 128, 1e-10, -448.0, 448.0, False)
+    assert np.array_equal(xq.cpu().view(torch.uint8).numpy(), g["quant_q"])
+    assert np.array_equal(xs.cpu().numpy().view(np.uint32), g["quant_s"].view(np.uint32))
+    # the MoE executor's column-major padded scale layout (fp8_eps_executor.py:52-55)
+    E, mp = 4, (M + 4 * 31) // 32 * 32
+    xs2 = torch.zeros((K // 128, mp), dtype=torch.float32, device=DEV).permute(-1, -2)
+    xq2 = torch.empty_like(xq)
+    flashinfer.quantization.quant_1x128(x, xq2, xs2, torch.zeros(E + 1, dtype=torch.int32, device=DEV), E, (M + 3) // 4 * 4, mp, K)
+    assert torch.equal(xq2.view(torch.uint8), xq.view(torch.uint8)) and torch.equal(xs2[:M].contiguous(), xs)
+
+
+def test_silu_and_mul_bit_exact_vs_reference_golden():
+    import flashinfer
+    from eps.executor import silu
+
+    g = load_golden("gemm_block_fp8.npz")
+    x = bf16_from_u16(g["silu_x"]).to(DEV)
+    ref = bf16_from_u16(g["silu_out"])
+    out = torch.empty(x.shape[0], x.shape[1] // 2, dtype=torch.bfloat16, device=DEV)
+    flashinfer.silu_and_mul(x, out)
+    assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
+    assert torch.equal(silu(x, None, 0).cpu().view(torch.int16), ref.view(torch.int16))
+    # fused silu + 1x128 quant == oracle quant of the bf16 result
+    gen = torch.Generator().manual_seed(3)
+    y = (torch.randn(37, 512, generator=gen) * 2).to(torch.bfloat16)
+    q = torch.empty(37, 256, dtype=torch.float8_e4m3fn, device=DEV)
+    s = torch.empty(37, 2, dtype=torch.float32, device=DEV)
+    flashinfer.activation.silu_and_mul_fuse_block_quant(y.to(DEV), s, q, True)
+    rq, rs = gemm_ref.per_token_group_quant_fp8(gemm_ref.silu_and_mul(y), 128)
+    assert torch.equal(q.cpu().view(torch.uint8), rq.view(torch.uint8)) and torch.equal(s.cpu(), rs)
+
+
+# ------------------------------------------------------------------ G4 dense
+def test_dense_gemm_vs_reference_golden():
+    import deep_gemm
+
+    g = load_golden("gemm_block_fp8.npz")
+    A, B = fp8_from_u8(g["mm_A"]).to(DEV), fp8_from_u8(g["mm_B"]).to(DEV)
+    As, Bs = torch.from_numpy(g["mm_As"]).to(DEV), torch.from_numpy(g["mm_Bs"]).to(DEV)
+    C = torch.empty(A.shape[0], B.shape[0], dtype=torch.bfloat16, device=DEV)
+    deep_gemm.gemm_fp8_fp8_bf16_nt((A, As), (B, Bs), C, True)
+    # reference threshold: rel-MAE < 1e-3 (python/sglang/test/test_block_fp8.py:185-189)
+    assert rel_mae(C.cpu(), bf16_from_u16(g["mm_C"])) < 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 128), (5, 2112, 7168), (130, 384, 512), (257, 7168, 2048), (64, 260, 256)])
+def test_dense_gemm_shapes(M, N, K):
+    import deep_gemm
+    from fluent_mi355.gemm import per_token_group_quant_fp8
+
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    W = fp8_weights(g, N, K)
+    Ws = torch.rand((N + 127) // 128, K // 128, generator=g) * 1e-2
+    xq, xs = per_token_group_quant_fp8(x.to(DEV), column_major_scales=True)   # TMA-aligned col-major like deep_geem.py
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    deep_gemm.gemm_fp8_fp8_bf16_nt((xq, xs), (W.to(DEV), Ws.to(DEV)), out)
+    rq, rs = gemm_ref.per_token_group_quant_fp8(x, 128)
+    assert torch.equal(xq.cpu().view(torch.uint8), rq.view(torch.uint8)) and torch.equal(xs.cpu().contiguous(), rs)
+    ref = gemm_ref.block_fp8_matmul(rq, W, rs, Ws)
+    assert rel_mae(out.cpu(), ref) < 1e-3, (M, N, K)
+
+
+# ------------------------------------------------------------------ G1 offset / G2 contiguous / G3 masked
+def make_group_case(counts, N, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    E, M = len(counts), sum(counts)
+    x = (torch.randn(M, K, generator=g) / 3).to(torch.bfloat16)
+    xq, xs = gemm_ref.per_token_group_quant_fp8(x, 128)
+    W = fp8_weights(g, E, N, K)
+    Ws = torch.rand(E, (N + 127) // 128, K // 128, generator=g) * 1e-2
+    ex = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32)
+    return xq, xs, W, Ws, ex
+
+
+@pytest.mark.parametrize("counts,N,K", [([4, 0, 7, 1], 256, 512), ([0, 0, 33, 0, 64, 1, 200], 512, 256),
+                                        ([3] * 32, 4096, 7168), ([150, 70], 7168, 2048), ([0, 0, 0], 128, 128)])
+def test_grouped_offset_vs_oracle(counts, N, K):
+    import deep_gemm
+
+    xq, xs, W, Ws, ex = make_group_case(counts, N, K, seed=len(counts) + N)
+    M, E = xq.shape[0], len(counts)
+    mp = (M + E * 31) // 32 * 32 + 32
+    xs_dev = torch.zeros((K // 128, mp), dtype=torch.float32, device=DEV).permute(-1, -2)   # executor's layout
+    xs_dev[:M] = xs.to(DEV)
+    out = torch.full((M + 3, N), 7.0, dtype=torch.bfloat16, device=DEV)     # rows past ex[-1] must stay untouched
+    deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset((xq.to(DEV), xs_dev[:M]), (W.to(DEV), Ws.to(DEV)), out[:M], ex.to(DEV),
+                                                    use_pdl=True)
+    ref = gemm_ref.grouped_gemm_offset(xq, xs, W, Ws, ex)
+    if M:
+        assert rel_mae(out[:M].cpu(), ref) < 1e-3
+    assert bool((out[M:] == 7.0).all())
+
+
+def test_grouped_contiguous_and_masked_vs_oracle():
+    import deep_gemm
+
+    counts = [128, 256, 0, 128]
+    N, K = 384, 512
+    xq, xs, W, Ws, ex = make_group_case(counts, N, K, seed=9)
+    M = xq.shape[0]
+    m_indices = torch.repeat_interleave(torch.arange(len(counts)), torch.tensor(counts)).to(torch.int32)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous((xq.to(DEV), xs.to(DEV)), (W.to(DEV), Ws.to(DEV)), out, m_indices.to(DEV), True)
+    ref = gemm_ref.grouped_gemm_contiguous(xq, xs, W, Ws, m_indices)
+    assert rel_mae(out.cpu(), ref) < 1e-3
+    # masked: [G, Mp, K] with only the first masked_m[g] rows valid; NaN-poison the padding rows of A
+    G, Mp = 3, 96
+    masked = torch.tensor([5, 0, 96], dtype=torch.int32)
+    g = torch.Generator().manual_seed(4)
+    xm = (torch.randn(G, Mp, K, generator=g) / 3).to(torch.bfloat16)
+    aq, asc = gemm_ref.per_token_group_quant_fp8(xm, 128)
+    aq_dev = aq.clone().view(torch.uint8)
+    for gi in range(G):
+        aq_dev[gi, int(masked[gi]):] = 0x7F
+    om = torch.full((G, Mp, N), 3.0, dtype=torch.bfloat16, device=DEV)
+    deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_masked((aq_dev.to(DEV).view(torch.float8_e4m3fn), asc.to(DEV)), (W[:G].to(DEV), Ws[:G].to(DEV)),
+                                                    om, masked.to(DEV), 32, True)
+    refm = gemm_ref.grouped_gemm_masked(aq, asc, W[:G], Ws[:G], masked)
+    for gi in range(G):
+        mm = int(masked[gi])
+        if mm:
+            assert rel_mae(om[gi, :mm].cpu(), refm[gi, :mm]) < 1e-3
+        assert bool((om[gi, mm:] == 3.0).all())
+
+
+def test_moe_pipeline_vs_reference_golden():
+    """Q1 -> G1(w13) -> A1 -> Q1 -> G1(w2) -> weighted sum (fp8_eps_executor.py:33-82) vs the reference's
+    torch_w8a8_block_fp8_moe output (python/sglang/test/test_block_fp8.py:212-241); threshold 2e-2 (:310-314)."""
+    import deep_gemm
+    import flashinfer
+    from eps.executor import silu
+
+    g = load_golden("gemm_block_fp8.npz")
+    a = bf16_from_u16(g["moe_a"])
+    w1, w2 = fp8_from_u8(g["moe_w1"]), fp8_from_u8(g["moe_w2"])
+    w1s, w2s = torch.from_numpy(g["moe_w1_s"]), torch.from_numpy(g["moe_w2_s"])
+    tw, ti = torch.from_numpy(g["moe_topk_w"]), torch.from_numpy(g["moe_topk_ids"]).long()
+    B, D = a.shape
+    E, topk = w1.shape[0], ti.shape[1]
+    flat = ti.reshape(-1)
+    order = torch.argsort(flat, stable=True)
+    rows = a.repeat_interleave(topk, dim=0)[order].contiguous().to(DEV)       # routed rows sorted by expert
+    ex = torch.zeros(E + 1, dtype=torch.int32)
+    ex[1:] = torch.cumsum(torch.bincount(flat, minlength=E), 0)
+    M = rows.shape[0]
+    mp = (M + E * 31) // 32 * 32
+
+    def q(x, K):
+        xq = torch.empty(M, K, dtype=torch.float8_e4m3fn, device=DEV)
+        xs = torch.empty((K // 128, mp), dtype=torch.float32, device=DEV).permute(-1, -2)
+        flashinfer.quantization.quant_1x128(x, xq, xs, ex.to(DEV), E, (M + 3) // 4 * 4, mp, K)
+        return xq, xs
+
+    gate_up = torch.empty(M, w1.shape[1], dtype=torch.bfloat16, device=DEV)
+    deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset(q(rows, D), (w1.to(DEV), w1s.to(DEV)), gate_up, ex.to(DEV), use_pdl=True)
+    act = silu(gate_up, ex.to(DEV), M)
+    down = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset(q(act, w2.shape[2]), (w2.to(DEV), w2s.to(DEV)), down, ex.to(DEV), use_pdl=True)
+    unsorted = torch.empty_like(down)
+    unsorted[order.to(DEV)] = down
+    out = (unsorted.view(B, topk, D) * tw.to(DEV).view(B, topk, 1).to(torch.bfloat16)).sum(dim=1)
+    assert rel_mae(out.cpu(), bf16_from_u16(g["moe_out"])) < 2e-2
+
+
+def test_gemm_graph_capture():
+    import deep_gemm
+
+    xq, xs, W, Ws, ex = make_group_case([9, 0, 40], 256, 256, seed=2)
+    args = ((xq.to(DEV), xs.to(DEV)), (W.to(DEV), Ws.to(DEV)))
+    out = torch.zeros(xq.shape[0], 256, dtype=torch.bfloat16, device=DEV)
+    exd = ex.to(DEV)
+    deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset(*args, out, exd)
+    eager = out.clone()
+    out.zero_()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset(*args, out, exd)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset(*args, out, exd)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
