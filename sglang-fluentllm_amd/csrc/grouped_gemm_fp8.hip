@@ -24,7 +24,6 @@ namespace {
 
 constexpr int BN = 128;            // weight rows per workgroup (= one 128-row scale block)
 constexpr int BK = 128;            // k block (bytes per row per stage)
-constexpr int kStages = 4;
 constexpr int kWBytes = BN * BK;   // 16 KiB
 constexpr int kUnit = 0x7F;
 
@@ -49,8 +48,13 @@ __device__ __forceinline__ v8i mk8(uint4 a, uint4 b) {
 
 template <int MT>
 struct Smem {
+  // ring depth: small token tiles (decode regime, short K) run 2 workgroups per CU with 3 stages each so that one
+  // workgroup's prologue/epilogue overlaps the other's steady state; the 128-token tile owns the CU with 4 stages
+  static constexpr int kStages = MT == 4 ? 4 : 3;
   static constexpr int kABytes = MT * 32 * BK;
   static constexpr int kAsFloats = MT * 32 < 64 ? 64 : MT * 32;
+  static constexpr int kAsPieces = kAsFloats / 64;
+  static constexpr int kPiecesPerWave = 4 + MT + kAsPieces;          // LDS-DMA instructions per wave per stage
   static constexpr int kStageBytes = kWBytes + kABytes + kAsFloats * 4;
   static constexpr int kTotal = kStages * kStageBytes;
 };
@@ -69,9 +73,9 @@ __device__ __forceinline__ void kblock_body(v16f (&acc)[MT], const uint8_t* __re
                                             const float ws, const int (&rb)[4], const int wave, const int li) {
   constexpr int kAsPieces = Smem<MT>::kAsFloats / 64;
   // ---- stage kb landed for every wave; stages kb+1, kb+2 (issued later) may stay in flight ----
-  if (more_in_flight) {
-    if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");        // 2 stages x (4 + 1 + 1) pieces
-    else if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");   // 2 x (4 + 2 + 1)
+  if (more_in_flight) {   // leave the (kStages - 2) later stages in flight
+    if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // 1 stage x (4 + 1 + 1) pieces
+    else if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");    // 1 x (4 + 2 + 1)
     else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");                          // 2 x (4 + 4 + 2)
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -116,12 +120,14 @@ __device__ __forceinline__ void kblock_body(v16f (&acc)[MT], const uint8_t* __re
 }
 
 template <int MT>
-__global__ __launch_bounds__(256, 1) void grouped_gemm_fp8_kernel(const GemmParams p, const uint8_t* __restrict__ gA,
+__global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void grouped_gemm_fp8_kernel(const GemmParams p, const uint8_t* __restrict__ gA,
                                                                    const float* __restrict__ gAs,
                                                                    const uint8_t* __restrict__ gW,
                                                                    const float* __restrict__ gWs,
                                                                    const int32_t* __restrict__ gmeta) {
   constexpr int BM = 32 * MT;
+  constexpr int kStages = Smem<MT>::kStages;
+  static_assert(Smem<MT>::kPiecesPerWave * (kStages - 2) == (MT == 1 ? 6 : MT == 2 ? 7 : 20), "vmcnt immediates");
   __shared__ __attribute__((aligned(16))) uint8_t smem[Smem<MT>::kTotal];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void grouped_gemm_fp8_kernel(const GemmPara
     const int nst = (kb + kStages - 1) % kStages;
     kblock_body<MT>(acc, stage_w(st), stage_a(st), stage_as(st), stage_w(nst), stage_a(nst), stage_as(nst), wsrc, asrc,
                     assrc, (long long)(kb + kStages - 1) * BK, (long long)(kb + kStages - 1) * p.as_stride_k,
-                    kb + kStages - 1 < KB, kb + 2 < KB, wsrow[kb], rb, wave, li);
+                    kb + kStages - 1 < KB, kb + kStages - 2 < KB, wsrow[kb], rb, wave, li);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
