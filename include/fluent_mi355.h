@@ -67,7 +67,8 @@ typedef struct FlMlaDecodeArgs {
   int32_t causal;           /* query j sees keys [0, seqlen-(s_q-1-j)) when causal */
   int32_t num_parts;        /* rows of tile_scheduler_metadata */
   float softmax_scale;
-  float descale_q, descale_k; /* FL_KV_FP8_576 only */
+  const float* descale_q;   /* FL_KV_FP8_576 only: DEVICE scalars (flashmla_backend.py:237-238), NULL = 1.0 */
+  const float* descale_k;
   /* query */
   const void* q_nope;       /* fp8 [bs,s_q,h_q,d_nope] (per-token) | fp8/bf16 [bs,s_q,h_q,576] */
   const void* q_rope;       /* bf16 [bs,s_q,h_q,d_rope] (per-token only) */

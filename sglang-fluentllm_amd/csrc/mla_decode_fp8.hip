@@ -69,6 +69,8 @@ constexpr int kDmaNopePerTile = 32;           // 1-KiB pieces per page
 struct Params {
   int bs, s_q, h_q, rows, causal, num_parts, row_groups;
   float scale_log2e;
+  const float* descale_q;   // FL_KV_FP8_576 only (device scalars, may be null = 1)
+  const float* descale_k;
   long long num_pages;
   long long bt_stride;
   uint16_t* out;
@@ -112,9 +114,12 @@ struct ReqState {
 };
 
 // One page of one request for one wave.  All LDS regions are distinct __restrict__ parameters (see file header).
-template <int NRG>
+// FMT 0: per-token FP8 (u8 [.,512] + f32 scale + bf16 rope [.,64]); FMT 1: one fp8 [.,576] tensor, scalar descales
+// (flashmla_backend.py:227-239): same pipeline, the 64 rope dims are a 9th fp8 k-step and the scales are constants.
+template <int NRG, int FMT>
 __device__ __forceinline__ void tile_body(
-    ReqState& st, const LaneConst& lc, const v8i (&qn)[8], const v8bf (&qr)[4], const float qs, const int W,
+    ReqState& st, const LaneConst& lc, const v8i (&qn)[8], const v8bf (&qr)[4], const v8i qr8, const float qs,
+    const float ks_const, const int W,
     const int rg, const int wave,
     // ---- LDS regions consumed now
     const uint8_t* __restrict__ rd_nope, const uint8_t* __restrict__ rd_rope, const float* __restrict__ rd_scale,
@@ -127,7 +132,7 @@ __device__ __forceinline__ void tile_body(
     const int tok0, const int L, const int L_row, const int L_min, const bool more_in_flight) {
   constexpr int NW = 2 * NRG;
   constexpr int kNopePerWave = kDmaNopePerTile / NW;
-  constexpr int kRopePerWave = 8 / NW;
+  constexpr int kRopePerWave = (FMT == 0 ? 8 : 4) / NW;
   const int lane = lc.lane, li = lc.li, lh = lc.lh;
 #ifdef FL_EXP_NOCOMPUTE   // experiment: DMA pipeline only (streaming ceiling of this structure)
   if (more_in_flight)
@@ -137,7 +142,7 @@ __device__ __forceinline__ void tile_body(
   __builtin_amdgcn_s_barrier();
   if (src_rope != nullptr) {
     for (int k = 0; k < kRopePerWave; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_rope + lc.dr[k]),
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const uint8_t*>(src_rope) + lc.dr[k]),
                                        (lds_ptr_t)(dma_rope + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
   }
@@ -160,7 +165,7 @@ __device__ __forceinline__ void tile_body(
 
   // ---- per-token scale preprocessing: lanes 0..31 handle the 32 tokens of this wave's half ----
   {
-    float ks = rd_scale[32 * W + li];
+    float ks = FMT == 0 ? rd_scale[32 * W + li] : ks_const;
     if (tok0 + 32 * W + li >= L || !(ks > 0.f) || !(ks < 3.0e38f)) ks = 1.f;
     if (lh == 0) {
       scratch[li] = ks;
@@ -176,10 +181,10 @@ __device__ __forceinline__ void tile_body(
   __builtin_amdgcn_sched_barrier(0);
   float4 ks4[4], lk4[4], ik4[4];
   {
-    const uint8_t* rp = rd_rope + W * (32 * kDR * 2);
+    const uint8_t* rp = rd_rope + W * (32 * (FMT == 0 ? kDR * 2 : kDR));
     uint4 ra[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) ra[s] = *reinterpret_cast<const uint4*>(rp + lc.rb[s]);
+    for (int s = 0; s < (FMT == 0 ? 4 : 2); ++s) ra[s] = *reinterpret_cast<const uint4*>(rp + lc.rb[s]);
     const uint8_t* kp = rd_nope + W * (32 * kDN);
     uint4 ka[8][2];
 #pragma unroll
@@ -196,14 +201,19 @@ __device__ __forceinline__ void tile_body(
       lk4[g] = *reinterpret_cast<const float4*>(scratch + 32 + tb);
       ik4[g] = *reinterpret_cast<const float4*>(scratch + 64 + tb);
     }
+    if constexpr (FMT == 0) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ra[s]), qr[s], acc, 0, 0, 0);
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ra[s]), qr[s], acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ra[0], ra[1]), qr8, acc, 0, 0, 0, kUnitScale, 0,
+                                                            kUnitScale);
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s)
       acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc, 0, 0, 0,
                                                             kUnitScale, 0, kUnitScale);
-    __builtin_amdgcn_sched_group_barrier(0x100, 32, 0);   // DS reads: 20 operand + 12 scale
-    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);   // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, FMT == 0 ? 32 : 30, 0);   // DS reads: operands + 12 scale
+    __builtin_amdgcn_sched_group_barrier(0x008, FMT == 0 ? 12 : 9, 0);    // MFMA
   }
   __builtin_amdgcn_sched_barrier(0);
   // V^T operands of the first PV tiles: issued now, they land under the softmax
@@ -310,9 +320,10 @@ __device__ __forceinline__ void tile_body(
 #endif
 #pragma unroll
     for (int k = 0; k < kRopePerWave; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_rope + lc.dr[k]),
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const uint8_t*>(src_rope) + lc.dr[k]),
                                        (lds_ptr_t)(dma_rope + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
+    if constexpr (FMT == 0)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
   }
 #ifdef FL_EXP_NODMA
   if (false) {
@@ -358,13 +369,15 @@ __device__ __forceinline__ void tile_body(
 
 // Read-only inputs are separate `const __restrict__` kernel arguments so that hipcc proves them invariant: wave-
 // uniform reads (page ids, lengths, scheduler rows) become s_load (lgkmcnt), never vector loads on the vmcnt queue.
-template <int NRG>
+template <int NRG, int FMT>
 __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
     const Params p, const int32_t* __restrict__ g_block_table, const int32_t* __restrict__ g_seqlens,
     const int32_t* __restrict__ g_meta, const int32_t* __restrict__ g_num_splits,
     const uint8_t* __restrict__ g_k_nope, const uint16_t* __restrict__ g_k_rope, const float* __restrict__ g_k_scale,
     const uint8_t* __restrict__ g_q_nope, const uint16_t* __restrict__ g_q_rope, const float* __restrict__ g_q_scale) {
   constexpr int NW = 2 * NRG;
+  constexpr int kTokBytes = FMT == 0 ? kDN : kDN + kDR;    // bytes per token row of the latent tensor in HBM
+  constexpr int kRopeTok = FMT == 0 ? kDR * 2 : kDR;        // bytes per token of rope (bf16 / fp8)
   __shared__ __attribute__((aligned(16))) uint8_t smem[kLdsBytes];
 
   const int tid = threadIdx.x;
@@ -387,8 +400,14 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
         lc.kb[e][k2] = li * kDN + (((((k2 ^ (kx >> 2)) << 2) | ((2 * lh + e) ^ (kx & 3))) << 4));
     // rope operand: token T = 32W + li (W*32 rows is a multiple of 16 -> same swizzle), 16-B chunk 2s + lh stored
     // at chunk (2s+lh) ^ ((T>>1)&7)
+    if constexpr (FMT == 0) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) lc.rb[s] = li * (kDR * 2) + ((((2 * s + lh) ^ ((li >> 1) & 7))) << 4);
+      for (int s = 0; s < 4; ++s) lc.rb[s] = li * (kDR * 2) + ((((2 * s + lh) ^ ((li >> 1) & 7))) << 4);
+    } else {
+      // fp8 rope: 64 B per token = 4 chunks; this lane reads chunks 2lh, 2lh+1, stored at chunk ^ ((T>>2)&3)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) lc.rb[s] = li * kDR + ((((2 * lh + (s & 1)) ^ ((li >> 2) & 3))) << 4);
+    }
     // V^T: B-operand byte q of lane (row n, half lh) is P of token 32(q>>4) + 4lh + (q&3) + 8((q&15)>>2) (bytes 0..15
     // = wave 0's 16 values of that lane, 16..31 = wave 1's).  tr8 read u covers q = 8u..8u+7: source lane
     // s16 = lane&15 reads 8 B of token T = 4lh + tok_in8 + 16(u&1) + 32(u>>1) (immediates), chunk
@@ -406,16 +425,21 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
   }
   {
     constexpr int kNopePerWave = kDmaNopePerTile / NW;
-    constexpr int kRopePerWave = 8 / NW;
+    constexpr int kRopePerWave = (FMT == 0 ? 8 : 4) / NW;
 #pragma unroll
     for (int k = 0; k < kNopePerWave; ++k) {
       const int T = ((wave * kNopePerWave + k) * 2 + lc.lh);   // token row this lane fills
-      lc.dn[k] = (unsigned)(T * kDN + ((lc.li ^ (T & 15)) << 4));
+      lc.dn[k] = (unsigned)(T * kTokBytes + ((lc.li ^ (T & 15)) << 4));
     }
 #pragma unroll
-    for (int k = 0; k < kRopePerWave; ++k) {
-      const int T = (wave * kRopePerWave + k) * 8 + (lc.lane >> 3);   // 8 token rows of 128 B per piece
-      lc.dr[k] = (unsigned)(T * kDR + (((lc.lane & 7) ^ ((T >> 1) & 7)) << 3));
+    for (int k = 0; k < kRopePerWave; ++k) {   // BYTE offsets inside the page's rope block
+      if constexpr (FMT == 0) {
+        const int T = (wave * kRopePerWave + k) * 8 + (lc.lane >> 3);   // 8 token rows of 128 B per piece
+        lc.dr[k] = (unsigned)(T * 128 + (((lc.lane & 7) ^ ((T >> 1) & 7)) << 4));
+      } else {
+        const int T = (wave * kRopePerWave + k) * 16 + (lc.lane >> 2);  // 16 token rows of 64 B per piece
+        lc.dr[k] = (unsigned)(T * kTokBytes + kDN + (((lc.lane & 3) ^ ((T >> 2) & 3)) << 4));
+      }
     }
   }
   const int lane = lc.lane, li = lc.li, lh = lc.lh;
@@ -459,24 +483,32 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
     const long long qrow = (long long)req * p.rows + row;
     v8i qn[8];
     v8bf qr[4];
+    v8i qr8 = v8i{0, 0, 0, 0, 0, 0, 0, 0};
     float qs = 0.f;
+    float ks_const = 1.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qr[s] = as_bf8(make_uint4(0, 0, 0, 0));
+    if constexpr (FMT == 1) ks_const = p.descale_k ? *p.descale_k : 1.f;
     if (row_ok) {
-      const uint8_t* qp = g_q_nope + qrow * kDN + lh * 32;
+      const uint8_t* qp = g_q_nope + qrow * kTokBytes + lh * 32;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const uint4 a = *reinterpret_cast<const uint4*>(qp + s * 64);
         const uint4 b = *reinterpret_cast<const uint4*>(qp + s * 64 + 16);
         qn[s] = make_v8i(a, b);
       }
-      const uint16_t* rp = g_q_rope + qrow * kDR + lh * 8;
+      if constexpr (FMT == 0) {
+        const uint16_t* rp = g_q_rope + qrow * kDR + lh * 8;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) qr[s] = as_bf8(*reinterpret_cast<const uint4*>(rp + s * 16));
-      qs = g_q_scale[qrow] * p.scale_log2e;
+        for (int s = 0; s < 4; ++s) qr[s] = as_bf8(*reinterpret_cast<const uint4*>(rp + s * 16));
+        qs = g_q_scale[qrow] * p.scale_log2e;
+      } else {
+        qr8 = make_v8i(*reinterpret_cast<const uint4*>(qp + 512), *reinterpret_cast<const uint4*>(qp + 528));
+        qs = (p.descale_q ? *p.descale_q : 1.f) * p.scale_log2e;
+      }
     } else {
 #pragma unroll
       for (int s = 0; s < 8; ++s) qn[s] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) qr[s] = as_bf8(make_uint4(0, 0, 0, 0));
     }
     int L_row = L;
     if (p.causal) L_row = L - (p.s_q - 1 - row / p.h_q);   // query j sees keys [0, L - (s_q-1-j))
@@ -508,21 +540,24 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
     // ---- prologue: [r0 s0 n0] [r1 s1 n1] [n2] ----
     {
       constexpr int kNopePerWave = kDmaNopePerTile / NW;
-      constexpr int kRopePerWave = 8 / NW;
+      constexpr int kRopePerWave = (FMT == 0 ? 8 : 4) / NW;
       auto dma_rs = [&](int t) {
         const long long pg = page_of(t);
-        const uint16_t* sr = g_k_rope + pg * (kPage * kDR);
-        const float* ss = g_k_scale + pg * kPage;
+        const uint8_t* sr = FMT == 0 ? reinterpret_cast<const uint8_t*>(g_k_rope) + pg * (kPage * kRopeTok)
+                                     : g_k_nope + pg * (kPage * kTokBytes);
         uint8_t* dr = smem + kOffRope + (t & 1) * kRopeBytes;
-        float* ds = reinterpret_cast<float*>(smem + kOffScale + (t & 1) * (kPage * 4));
 #pragma unroll
         for (int k = 0; k < kRopePerWave; ++k)
           __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sr + lc.dr[k]), (lds_ptr_t)(dr + (wave * kRopePerWave + k) * 1024),
                                            16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ss + lane), (lds_ptr_t)ds, 4, 0, 0);
+        if constexpr (FMT == 0) {
+          const float* ss = g_k_scale + pg * kPage;
+          float* ds = reinterpret_cast<float*>(smem + kOffScale + (t & 1) * (kPage * 4));
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ss + lane), (lds_ptr_t)ds, 4, 0, 0);
+        }
       };
       auto dma_n = [&](int t) {
-        const uint8_t* sn = g_k_nope + page_of(t) * (kPage * kDN);
+        const uint8_t* sn = g_k_nope + page_of(t) * (kPage * kTokBytes);
         uint8_t* dn = smem + kOffRing + (t & 3) * kSlotBytes;
 #pragma unroll
         for (int k = 0; k < kNopePerWave; ++k)
@@ -532,11 +567,11 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
       if (n > 0) { dma_rs(0); dma_n(0); }
       if (n > 1) { dma_rs(1); dma_n(1); }
       if (n > 2) dma_n(2);
-      if (n > 2) {
-        if constexpr (NRG == 2)
-          asm volatile("s_waitcnt vmcnt(19)" ::: "memory");   // leave [r1 s1 n1] [n2] = (2+1+8) + 8 in flight
-        else
-          asm volatile("s_waitcnt vmcnt(37)" ::: "memory");   // (4+1+16) + 16
+      if (n > 2) {   // leave [r1 s1 n1] [n2] in flight
+        if constexpr (NRG == 2 && FMT == 0) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");        // (2+1+8) + 8
+        else if constexpr (NRG == 1 && FMT == 0) asm volatile("s_waitcnt vmcnt(37)" ::: "memory");   // (4+1+16) + 16
+        else if constexpr (NRG == 2 && FMT == 1) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");   // (1+0+8) + 8
+        else asm volatile("s_waitcnt vmcnt(34)" ::: "memory");                                       // (2+0+16) + 16
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -547,13 +582,18 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
       const uint8_t* sn = nullptr;
       const uint16_t* sr = nullptr;
       const float* ss = nullptr;
-      if (i + 3 < n) sn = g_k_nope + page_of(i + 3) * (kPage * kDN);
+      if (i + 3 < n) sn = g_k_nope + page_of(i + 3) * (kPage * kTokBytes);
       if (i + 2 < n) {
         const long long pg = page_of(i + 2);
-        sr = g_k_rope + pg * (kPage * kDR);
-        ss = g_k_scale + pg * kPage;
+        if constexpr (FMT == 0) {
+          sr = g_k_rope + pg * (kPage * kDR);
+          ss = g_k_scale + pg * kPage;
+        } else {
+          sr = reinterpret_cast<const uint16_t*>(g_k_nope + pg * (kPage * kTokBytes));
+          ss = reinterpret_cast<const float*>(sr);   // unused (non-null)
+        }
       }
-      tile_body<NRG>(st, lc, qn, qr, qs, W, rg, wave,
+      tile_body<NRG, FMT>(st, lc, qn, qr, qr8, qs, ks_const, W, rg, wave,
                      smem + kOffRing + (i & 3) * kSlotBytes, smem + kOffRope + (i & 1) * kRopeBytes,
                      reinterpret_cast<const float*>(smem + kOffScale + (i & 1) * (kPage * 4)), scratch,
                      smem + kOffPbuf + (i & 1) * kPbufPerParity,
@@ -668,11 +708,13 @@ __global__ __launch_bounds__(256) void mla_combine_kernel(const Params p, const 
 
 }  // namespace
 
-int fl_mla_decode_fp8_per_token_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
+int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
+  const bool per_token = a->kv_format == FL_KV_FP8_PER_TOKEN;
   FL_CHECK_ARG(a->d_nope == kDN && a->d_rope == kDR, "fl_mla_decode: only d_nope=512,d_rope=64 (got %d,%d)",
                a->d_nope, a->d_rope);
-  FL_CHECK_ARG(a->q_nope && a->q_rope && a->q_scale && a->k_nope && a->k_rope && a->k_scale,
-               "fl_mla_decode(per-token fp8): null q/k pointer");
+  FL_CHECK_ARG(a->q_nope && a->k_nope, "fl_mla_decode: null q/k pointer");
+  FL_CHECK_ARG(!per_token || (a->q_rope && a->q_scale && a->k_rope && a->k_scale),
+               "fl_mla_decode(per-token fp8): null rope/scale pointer");
   FL_CHECK_ARG(a->block_table && a->cache_seqlens && a->tile_scheduler_metadata && a->num_splits && a->out && a->lse &&
                    a->o_accum && a->lse_accum,
                "fl_mla_decode: null metadata/output pointer");
@@ -682,30 +724,27 @@ int fl_mla_decode_fp8_per_token_impl(const FlMlaDecodeArgs* a, hipStream_t strea
   p.bs = a->bs; p.s_q = a->s_q; p.h_q = a->h_q; p.rows = a->s_q * a->h_q; p.causal = a->causal;
   p.num_parts = a->num_parts;
   p.scale_log2e = a->softmax_scale * kLog2e;
+  p.descale_q = a->descale_q; p.descale_k = a->descale_k;
   p.num_pages = a->num_pages; p.bt_stride = a->block_table_stride;
   p.out = (uint16_t*)a->out; p.lse = a->lse; p.o_accum = a->o_accum; p.lse_accum = a->lse_accum;
   // rows <= 32 (e.g. the TP8 shard, H=16): one row group per workgroup (2 waves); otherwise 2 row groups (4 waves).
   // FL_MLA_ROWS_PER_WG (= 64) only sizes the scheduler's part count; both shapes give 1 row group for rows <= 32.
   const int nrg = p.rows > 32 ? 2 : 1;
   p.row_groups = (p.rows + 32 * nrg - 1) / (32 * nrg);
-  const unsigned grid = (unsigned)(p.num_parts * p.row_groups);
-  if (nrg == 2)
-    mla_decode_fp8_kernel<2><<<dim3(grid), dim3(256), 0, stream>>>(
-        p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, a->num_splits, (const uint8_t*)a->k_nope,
-        (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
-  else
-    mla_decode_fp8_kernel<1><<<dim3(grid), dim3(128), 0, stream>>>(
-        p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, a->num_splits, (const uint8_t*)a->k_nope,
-        (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
+  const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(128 * nrg);
+#define FL_LAUNCH(NRG_, FMT_)                                                                                          \
+  mla_decode_fp8_kernel<NRG_, FMT_><<<grid, block, 0, stream>>>(                                                       \
+      p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, a->num_splits, (const uint8_t*)a->k_nope,        \
+      (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale)
+  if (per_token) {
+    if (nrg == 2) FL_LAUNCH(2, 0); else FL_LAUNCH(1, 0);
+  } else {
+    if (nrg == 2) FL_LAUNCH(2, 1); else FL_LAUNCH(1, 1);
+  }
+#undef FL_LAUNCH
   FL_CHECK_LAUNCH("mla_decode_fp8_kernel");
   const long long waves = (long long)p.bs * p.rows;
   mla_combine_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(p, a->num_splits);
   FL_CHECK_LAUNCH("mla_combine_kernel");
   return FL_OK;
 }
-
-#ifdef FL_MLA_DEBUG
-extern "C" int fl_mla_debug_set_buffer(int* dev_ptr) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &dev_ptr, sizeof(dev_ptr));
-}
-#endif

@@ -18,7 +18,7 @@ class FlMlaDecodeArgs(ctypes.Structure):
         ("kv_format", ctypes.c_int32), ("bs", ctypes.c_int32), ("s_q", ctypes.c_int32), ("h_q", ctypes.c_int32),
         ("d_nope", ctypes.c_int32), ("d_rope", ctypes.c_int32), ("causal", ctypes.c_int32),
         ("num_parts", ctypes.c_int32),
-        ("softmax_scale", ctypes.c_float), ("descale_q", ctypes.c_float), ("descale_k", ctypes.c_float),
+        ("softmax_scale", ctypes.c_float), ("descale_q", _f32p), ("descale_k", _f32p),
         ("q_nope", _c_void_p), ("q_rope", _c_void_p), ("q_scale", _f32p),
         ("k_nope", _c_void_p), ("k_rope", _c_void_p), ("k_scale", _f32p),
         ("num_pages", ctypes.c_int64),

@@ -158,7 +158,6 @@ def flash_mla_ckv_fp8_per_token(q_nope: torch.Tensor, q_rope: torch.Tensor, k_ca
     a = FlMlaDecodeArgs()
     a.kv_format = KV_FP8_PER_TOKEN
     a.d_nope, a.d_rope = 512, 64
-    a.descale_q = a.descale_k = 1.0
     a.q_nope, a.q_rope, a.q_scale = q_nope.data_ptr(), q_rope.data_ptr(), q_scale.data_ptr()
     a.k_nope, a.k_rope, a.k_scale = k_cache_lora.data_ptr(), k_cache_rope.data_ptr(), k_scale.data_ptr()
     a.num_pages = k_cache_lora.shape[0]
@@ -184,13 +183,15 @@ def flash_mla_with_kvcache(q: torch.Tensor, k_cache: torch.Tensor, block_table: 
     if q.dtype == torch.bfloat16:
         _req(k_cache.dtype == torch.bfloat16, "bf16 q needs a bf16 cache")
         a.kv_format = KV_BF16_576
-        a.descale_q = a.descale_k = 1.0
     else:
         _req(q.dtype in _ONE_BYTE and k_cache.dtype in _ONE_BYTE, "fp8 q needs an fp8 cache")
         a.kv_format = KV_FP8_576
-        # scalar descales are host floats in the C-ABI; the reference passes torch.ones(1) (flashmla_backend.py:237-238)
-        a.descale_q = float(descale_q.item()) if descale_q is not None else 1.0
-        a.descale_k = float(descale_k.item()) if descale_k is not None else 1.0
+        # the reference passes device tensors torch.ones(1) (flashmla_backend.py:237-238): forwarded as device pointers,
+        # read inside the kernel (no .item(): the call stays graph-capturable)
+        for t in (descale_q, descale_k):
+            _req(t is None or (t.is_cuda and t.dtype == torch.float32 and t.numel() >= 1), "descales must be f32 device tensors")
+        a.descale_q = descale_q.data_ptr() if descale_q is not None else None
+        a.descale_k = descale_k.data_ptr() if descale_k is not None else None
     a.q_nope = q.data_ptr()
     a.k_nope = k_cache.data_ptr()
     a.num_pages = k_cache.shape[0]

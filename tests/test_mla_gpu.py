@@ -269,3 +269,48 @@ def test_graph_capture_replay(fm):
     c["q"] = q_static.cpu()
     o_ref, lse_e, ref, rlse, _ = run_decode(fm, c, 16)
     assert torch.equal(o.cpu().view(torch.int16), o_ref.view(torch.int16))
+
+
+# ---------------------------------------------------------------- K2: single fp8 [.,576] cache, scalar descales
+def make_fp8_576_case(lens, H, s_q, seed):
+    g = torch.Generator().manual_seed(seed)
+    bs = len(lens)
+    npg = [(max(L, 0) + 63) // 64 for L in lens]
+    pages = sum(npg) + 3
+    kc = torch.full((pages * 64, 1, 576), 0x7F, dtype=torch.uint8)       # NaN patterns outside the valid tokens
+    perm = (torch.randperm(pages - 1, generator=g) + 1).tolist()
+    bt = torch.zeros(bs, max(max(npg), 1) + 1, dtype=torch.int32)
+    pi = 0
+    for b, L in enumerate(lens):
+        for j in range(npg[b]):
+            bt[b, j] = perm[pi]
+            pi += 1
+        if L > 0:
+            t = torch.arange(L)
+            loc = bt[b, (t // 64).long()].long() * 64 + t % 64
+            kc[loc] = torch.randn(L, 1, 576, generator=g).to(torch.float8_e4m3fn).view(torch.uint8)
+    q = torch.randn(bs, s_q, H, 576, generator=g).to(torch.float8_e4m3fn)
+    return q, kc, bt, torch.tensor(lens, dtype=torch.int32), pages
+
+
+@pytest.mark.parametrize("lens,H,s_q,dq,dk", [([128], 16, 1, 1.0, 1.0), ([1, 63, 65, 300], 128, 1, 1.0, 1.0),
+                                               ([70, 4, 200], 16, 4, 0.5, 2.0), ([3000], 64, 1, 1.0, 1.0)])
+def test_flash_mla_with_kvcache_fp8(fm, lens, H, s_q, dq, dk):
+    q, kc, bt, seq, pages = make_fp8_576_case(lens, H, s_q, seed=H + s_q)
+    meta, ns = fm.get_mla_metadata(seq.to(dev()), s_q * H, 1)
+    dqt, dkt = torch.tensor([dq], device=dev()), torch.tensor([dk], device=dev())
+    o, lse = fm.flash_mla_with_kvcache(q=q.to(dev()), k_cache=kc.to(dev()).view(torch.float8_e4m3fn).view(pages, 64, 1, 576),
+                                       block_table=bt.to(dev()), cache_seqlens=seq.to(dev()), head_dim_v=512,
+                                       tile_scheduler_metadata=meta, num_splits=ns, softmax_scale=SCALE, causal=True,
+                                       descale_q=dqt, descale_k=dkt)
+    torch.cuda.synchronize()
+    ref, rlse = mla_ref.mla_decode_with_kvcache(q, kc.view(pages, 64, 1, 576), bt, seq, 512, SCALE, True, dq, dk)
+    check(o.cpu(), lse.cpu(), ref, rlse, f"fp8_576 {lens}")
+    # bit-level statement of the kernel: same arithmetic with constant scales and fp8 rope
+    bsz = len(lens)
+    emu, _ = mla_ref.mla_decode_fp8_per_token_emulated(
+        q[..., :512].contiguous(), torch.full((bsz, s_q, H, 1), dq), q[..., 512:].float(),
+        kc[..., :512].contiguous().view(pages, 64, 1, 512), torch.full((pages, 64, 1, 1), dk),
+        kc[..., 512:].contiguous().view(torch.float8_e4m3fn).float().view(pages, 64, 1, 64), bt, seq, SCALE, True)
+    e = (o.cpu().double() - emu).abs()
+    assert float(e.mean() / emu.abs().mean().clamp_min(1e-30)) < 3e-3
