@@ -132,6 +132,22 @@ int fl_quant_1x128(const void* x, int64_t M, int K, float eps, void* x_q, float*
 int fl_silu_and_mul(const void* x, int64_t M, int I, void* out_bf16, void* q_out, float* s_out, int64_t s_stride_m,
                     int64_t s_stride_k, fl_stream_t stream);
 
+/* ---- C1/C2: device side of eps.fast_ep.AllToAll.dispatch / combine (srt/layers/moe/dispatcher/fast_ep.py:45-51,
+ * 73-78).  The exchange is one equal-split all-to-all per direction over RCCL (host: torch.distributed); these do the
+ * integer / row work around it, sync-free with static shapes.  Rows are bf16 [*, hidden], hidden % 8 == 0. ---- */
+int fl_ep_route(const int32_t* indices /*[num_pairs] global expert ids*/, int64_t num_pairs, int experts_per_rank, int world,
+                int cap /*rows per peer slab*/, int32_t* send_slot /*[num_pairs] -> dest*cap+pos or -1*/,
+                int32_t* send_eid /*[world*cap] local expert id at the destination, -1 = empty*/, fl_stream_t stream);
+int fl_ep_sort(const int32_t* recv_eid /*[num_slots]*/, int64_t num_slots, int num_local_experts,
+               int32_t* order /*[num_slots] slots grouped by expert, invalid last*/, int32_t* exclusive_sum /*[E_l+1]*/,
+               fl_stream_t stream);
+int fl_ep_gather_rows(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int hidden, void* dst,
+                      int64_t dst_rows, fl_stream_t stream);   /* dst[i] = src[idx[i]] */
+int fl_ep_scatter_rows(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int hidden, void* dst,
+                       int64_t dst_rows, fl_stream_t stream);  /* dst[idx[i]] = src[i] */
+int fl_ep_combine(const void* ret_rows, int64_t num_ret_rows, const int32_t* send_slot, const float* weights,
+                  int64_t num_tokens, int top_k, int hidden, void* out, fl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,116 @@
+"""Host-side mirror of `eps.fast_ep.AllToAll` (reference: 3rdparty/eps over MSCCL++; call sites
+python/sglang/srt/layers/moe/dispatcher/fast_ep.py:16-22,45-51,73-78).
+
+MI355X mapping: xGMI is a point-to-point mesh, so the natural collective is ONE equal-split all-to-all per direction
+over RCCL (`torch.distributed.all_to_all_single`, backend "nccl" = RCCL) on fixed-capacity peer slabs — no counts
+exchange, no host sync, static shapes (hipGraph-friendly).  The integer/row work around the exchange runs in HIP
+kernels (csrc/ep_a2a.hip).  `row_ops` exists so that the multi-process HOST logic can be exercised on CPU tensors with
+the gloo backend in tests (tests/ inject a torch-indexing implementation); the product default is the HIP one and
+there is no automatic fallback."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class HipRowOps:
+    """Device implementation: every method is one C-ABI call on the current stream."""
+
+    def __init__(self):
+        import ctypes
+
+        from ._lib import check, lib, stream_ptr
+
+        self._ct, self._check, self._lib, self._stream = ctypes, check, lib, stream_ptr
+        vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+        lib.fl_ep_route.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp]
+        lib.fl_ep_sort.argtypes = [vp, i64, i32, vp, vp, vp]
+        lib.fl_ep_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
+        lib.fl_ep_scatter_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
+        lib.fl_ep_combine.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp]
+        for n in ("fl_ep_route", "fl_ep_sort", "fl_ep_gather_rows", "fl_ep_scatter_rows", "fl_ep_combine"):
+            getattr(lib, n).restype = i32
+
+    def route(self, indices, experts_per_rank, world, cap, send_slot, send_eid):
+        self._check(self._lib.fl_ep_route(indices.data_ptr(), indices.numel(), experts_per_rank, world, cap,
+                                          send_slot.data_ptr(), send_eid.data_ptr(), self._stream(indices.device)), "fl_ep_route")
+
+    def sort(self, recv_eid, num_local_experts, order, exclusive_sum):
+        self._check(self._lib.fl_ep_sort(recv_eid.data_ptr(), recv_eid.numel(), num_local_experts, order.data_ptr(),
+                                         exclusive_sum.data_ptr(), self._stream(recv_eid.device)), "fl_ep_sort")
+
+    def gather(self, src, idx, n, dst):
+        self._check(self._lib.fl_ep_gather_rows(src.data_ptr(), src.shape[0], idx.data_ptr(), n, src.shape[1], dst.data_ptr(),
+                                                dst.shape[0], self._stream(src.device)), "fl_ep_gather_rows")
+
+    def scatter(self, src, idx, n, dst):
+        self._check(self._lib.fl_ep_scatter_rows(src.data_ptr(), src.shape[0], idx.data_ptr(), n, src.shape[1], dst.data_ptr(),
+                                                 dst.shape[0], self._stream(src.device)), "fl_ep_scatter_rows")
+
+    def combine(self, ret, send_slot, weights, out, top_k):
+        self._check(self._lib.fl_ep_combine(ret.data_ptr(), ret.shape[0], send_slot.data_ptr(), weights.data_ptr(),
+                                            out.shape[0], top_k, out.shape[1], out.data_ptr(), self._stream(ret.device)),
+                    "fl_ep_combine")
+
+
+class AllToAll:
+    """AllToAll(top_k, num_experts, hidden_size, max_tokens, comm_ptr): `max_tokens` is the GLOBAL token capacity
+    (low_latency_max_num_tokens_per_gpu * world, fast_ep.py:20); `comm_ptr` (MSCCL++ communicator of the reference) is
+    accepted and ignored — the exchange runs on `group` (default: the world group) of torch.distributed."""
+
+    def __init__(self, top_k, num_experts, hidden_size, max_tokens, comm_ptr=None, group=None, row_ops=None):
+        self.top_k, self.num_experts, self.hidden = int(top_k), int(num_experts), int(hidden_size)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if self.num_experts % self.world:
+            raise RuntimeError("num_experts must divide evenly over the EP group")
+        self.experts_per_rank = self.num_experts // self.world
+        self.max_tokens_per_rank = max(1, int(max_tokens) // self.world)
+        self.cap = self.max_tokens_per_rank * self.top_k          # rows of one peer slab (worst case: all pairs to one peer)
+        self.row_ops = row_ops if row_ops is not None else HipRowOps()
+        self._state = None
+
+    def _a2a(self, out, inp):
+        if self.world == 1:
+            out.copy_(inp)
+        else:
+            dist.all_to_all_single(out, inp, group=self.group)   # equal splits: world slabs of `cap` rows
+
+    def dispatch(self, out_exclusive_sum, out_expert_x, dp_x, indices, num_global_tokens):
+        t = dp_x.shape[0]
+        if t > self.max_tokens_per_rank:
+            raise RuntimeError(f"{t} local tokens exceed the capacity {self.max_tokens_per_rank} this AllToAll was built for")
+        dev, S = dp_x.device, self.world * self.cap
+        idx = indices.reshape(-1).contiguous()
+        send_slot = torch.empty(idx.numel(), dtype=torch.int32, device=dev)
+        send_eid = torch.empty(S, dtype=torch.int32, device=dev)
+        self.row_ops.route(idx, self.experts_per_rank, self.world, self.cap, send_slot, send_eid)
+        # rows of pair p = (token p // top_k): gather through a pair->token index so that one kernel serves both uses
+        send_buf = torch.empty(S, self.hidden, dtype=dp_x.dtype, device=dev)
+        pair_tok = (torch.arange(idx.numel(), device=dev, dtype=torch.int32) // self.top_k)
+        rows = torch.empty(idx.numel(), self.hidden, dtype=dp_x.dtype, device=dev)
+        self.row_ops.gather(dp_x, pair_tok, idx.numel(), rows)
+        self.row_ops.scatter(rows, send_slot, idx.numel(), send_buf)
+        recv_buf = torch.empty_like(send_buf)
+        recv_eid = torch.empty_like(send_eid)
+        self._a2a(recv_buf, send_buf)
+        self._a2a(recv_eid, send_eid)
+        order = torch.empty(S, dtype=torch.int32, device=dev)
+        self.row_ops.sort(recv_eid, self.experts_per_rank, order, out_exclusive_sum)
+        n_out = min(out_expert_x.shape[0], S)
+        self.row_ops.gather(recv_buf, order, n_out, out_expert_x)
+        self._state = (send_slot, order, n_out, S)
+        return out_expert_x, out_exclusive_sum
+
+    def combine(self, out_tokens, weights, expert_y, num_global_tokens):
+        if self._state is None:
+            raise RuntimeError("combine() without a preceding dispatch()")
+        send_slot, order, n_out, S = self._state
+        dev = expert_y.device
+        back = torch.zeros(S, self.hidden, dtype=expert_y.dtype, device=dev)
+        self.row_ops.scatter(expert_y, order, n_out, back)
+        ret = torch.empty_like(back)
+        self._a2a(ret, back)
+        self.row_ops.combine(ret, send_slot, weights.to(torch.float32).contiguous(), out_tokens, self.top_k)
+        return out_tokens

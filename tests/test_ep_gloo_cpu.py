@@ -1,0 +1,68 @@
+"""CPU, world_size 2, gloo: the N>1 host logic of the path — EP all-to-all dispatch/combine (fast_ep.py:45-51,73-78
+semantics) and the bench's max-over-ranks timing reduction."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, t_per_rank):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "sglang-fluentllm_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("FLUENT_MI355_ALLOW_MISSING_LIB", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ep_torch_ops import TorchRowOps
+        from fluent_mi355.ep import AllToAll
+
+        E, K, HID = 8, 3, 64
+        g = torch.Generator().manual_seed(100 + rank)
+        t = t_per_rank[rank]
+        T_g = sum(t_per_rank)
+        x = torch.randn(t, HID, generator=g).to(torch.bfloat16)
+        idx = torch.stack([torch.randperm(E, generator=g)[:K] for _ in range(t)]).to(torch.int32) if t else torch.zeros(0, K, dtype=torch.int32)
+        w = torch.rand(t, K, generator=g)
+        a2a = AllToAll(K, E, HID, max(t_per_rank) * world, None, row_ops=TorchRowOps())
+        ex = torch.empty(E // world + 1, dtype=torch.int32)
+        expert_x = torch.zeros(T_g * K, HID, dtype=torch.bfloat16)
+        a2a.dispatch(out_exclusive_sum=ex, out_expert_x=expert_x, dp_x=x, indices=idx, num_global_tokens=T_g)
+        # exclusive_sum consistent with what every rank routed to my experts
+        all_idx = [None] * world
+        dist.all_gather_object(all_idx, idx.tolist())
+        flat = [e for r in all_idx for row in r for e in row]
+        mine = [sum(1 for e in flat if e == rank * (E // world) + le) for le in range(E // world)]
+        assert ex.tolist() == [0] + torch.cumsum(torch.tensor(mine), 0).tolist(), (ex.tolist(), mine)
+        # "expert compute": local expert le scales its rows by (global expert id + 1)
+        y = torch.zeros_like(expert_x)
+        for le in range(E // world):
+            lo, hi = int(ex[le]), int(ex[le + 1])
+            y[lo:hi] = (expert_x[lo:hi].float() * (rank * (E // world) + le + 1)).to(torch.bfloat16)
+        out = torch.empty(t, HID, dtype=torch.bfloat16)
+        a2a.combine(out_tokens=out, weights=w, expert_y=y, num_global_tokens=T_g)
+        ref = sum(w[:, k:k + 1] * (x.float() * (idx[:, k:k + 1].float() + 1)).to(torch.bfloat16).float() for k in range(K)).to(torch.bfloat16) if t else out
+        assert torch.allclose(out.float(), ref.float(), atol=2e-2, rtol=2e-2), float((out.float() - ref.float()).abs().max())
+        # bench.py's reduction: step time = MAX over ranks
+        tm = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        assert float(tm) == float(world)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("t_per_rank", [[5, 7], [0, 4]])
+def test_ep_all_to_all_world2_gloo(t_per_rank):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, t_per_rank), nprocs=2, join=True)

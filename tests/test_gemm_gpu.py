@@ -212,3 +212,30 @@ def test_gemm_graph_capture():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+def test_ep_all_to_all_single_rank_hip_row_ops():
+    """C1/C2 device kernels (route / sort / gather / scatter / combine) on one GPU (world 1: the exchange is a copy);
+    the multi-rank host logic is covered on CPU with gloo in test_ep_gloo_cpu.py."""
+    from eps.fast_ep import AllToAll
+
+    E, K, HID, t = 16, 4, 256, 37
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(t, HID, generator=g).to(torch.bfloat16)
+    idx = torch.stack([torch.randperm(E, generator=g)[:K] for _ in range(t)]).to(torch.int32)
+    w = torch.rand(t, K, generator=g)
+    a2a = AllToAll(K, E, HID, 64, None)
+    ex = torch.empty(E + 1, dtype=torch.int32, device=DEV)
+    expert_x = torch.zeros(t * K, HID, dtype=torch.bfloat16, device=DEV)
+    a2a.dispatch(out_exclusive_sum=ex, out_expert_x=expert_x, dp_x=x.to(DEV), indices=idx.to(DEV), num_global_tokens=t)
+    counts = torch.bincount(idx.reshape(-1).long(), minlength=E)
+    assert ex.cpu().tolist() == [0] + torch.cumsum(counts, 0).tolist()
+    exc = ex.cpu()
+    y = torch.zeros_like(expert_x)
+    for e in range(E):
+        y[int(exc[e]):int(exc[e + 1])] = (expert_x[int(exc[e]):int(exc[e + 1])].float() * (e + 1)).to(torch.bfloat16)
+        # every row grouped under expert e is a token that selected e
+    out = torch.empty(t, HID, dtype=torch.bfloat16, device=DEV)
+    a2a.combine(out_tokens=out, weights=w.to(DEV), expert_y=y, num_global_tokens=t)
+    ref = sum(w[:, k:k + 1] * (x.float() * (idx[:, k:k + 1].float() + 1)).to(torch.bfloat16).float() for k in range(K)).to(torch.bfloat16)
+    assert torch.allclose(out.cpu().float(), ref.float(), atol=2e-2, rtol=2e-2)
