@@ -79,8 +79,13 @@ struct Params {
   float* lse_accum;
 };
 
-#ifdef FL_MLA_DEBUG
+#if defined(FL_MLA_DEBUG) || defined(FL_MLA_TIMING)
 __device__ int* g_dbg = nullptr;   // debug builds only: set by fl_mla_debug_set_buffer
+#endif
+#ifdef FL_MLA_TIMING
+#define FL_T(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); tacc[i] += t__ - tlast; tlast = t__; } while (0)
+#else
+#define FL_T(i) do { } while (0)
 #endif
 
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -113,14 +118,50 @@ struct ReqState {
   float l_run, lq_run, m_w, m_o;   // own exact / rounded-P normalisers, own integer reference, reference of O
 };
 
+// Operands of a page's QK that are fetched one page early (in the shadow of the previous page's PV MFMAs).
+struct QkPrefetch {
+  uint4 ra[4];       // rope A operand (FMT 0: 4 bf16 k-steps; FMT 1: 2 x 16 B of the fp8 k-step)
+  uint4 ka[4][2];    // latent k-steps 0..3
+};
+
+// Per-token scale triples {k_scale, log2 k_scale, 1/k_scale} of this wave's 32 tokens -> wave-private scratch.
+template <int FMT>
+__device__ __forceinline__ void scale_prep(const float* __restrict__ rd_scale, float* __restrict__ scratch,
+                                           const float ks_const, const int W, const int li, const int lh, const int tok0,
+                                           const int L) {
+  float ks = FMT == 0 ? rd_scale[32 * W + li] : ks_const;
+  if (tok0 + 32 * W + li >= L || !(ks > 0.f) || !(ks < 3.0e38f)) ks = 1.f;
+  if (lh == 0) {
+    scratch[li] = ks;
+    scratch[32 + li] = __builtin_amdgcn_logf(ks);
+    scratch[64 + li] = __builtin_amdgcn_rcpf(ks);
+  }
+}
+
+template <int FMT>
+__device__ __forceinline__ void qk_prefetch(QkPrefetch& pre, const LaneConst& lc, const uint8_t* __restrict__ rd_nope,
+                                            const uint8_t* __restrict__ rd_rope, const int W) {
+  const uint8_t* rp = rd_rope + W * (32 * (FMT == 0 ? kDR * 2 : kDR));
+#pragma unroll
+  for (int s = 0; s < (FMT == 0 ? 4 : 2); ++s) pre.ra[s] = *reinterpret_cast<const uint4*>(rp + lc.rb[s]);
+  const uint8_t* kp = rd_nope + W * (32 * kDN);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    pre.ka[s][0] = *reinterpret_cast<const uint4*>(kp + lc.kb[0][s & 3]);
+    pre.ka[s][1] = *reinterpret_cast<const uint4*>(kp + lc.kb[1][s & 3]);
+  }
+}
+
 // One page of one request for one wave.  All LDS regions are distinct __restrict__ parameters (see file header).
 // FMT 0: per-token FP8 (u8 [.,512] + f32 scale + bf16 rope [.,64]); FMT 1: one fp8 [.,576] tensor, scalar descales
 // (flashmla_backend.py:227-239): same pipeline, the 64 rope dims are a 9th fp8 k-step and the scales are constants.
 template <int NRG, int FMT>
 __device__ __forceinline__ void tile_body(
-    ReqState& st, const LaneConst& lc, const v8i (&qn)[8], const v8bf (&qr)[4], const v8i qr8, const float qs,
-    const float ks_const, const int W,
-    const int rg, const int wave,
+    ReqState& st, QkPrefetch& pre, const LaneConst& lc, const v8i (&qn)[8], const v8bf (&qr)[4], const v8i qr8,
+    const float qs, const float ks_const, const int W, const int rg, const int wave,
+    // ---- LDS regions of the NEXT page (landed: certified by this call's barrier), read in the PV shadow
+    const uint8_t* __restrict__ nx_nope, const uint8_t* __restrict__ nx_rope, const float* __restrict__ nx_scale,
+    const bool has_next,
     // ---- LDS regions consumed now
     const uint8_t* __restrict__ rd_nope, const uint8_t* __restrict__ rd_rope, const float* __restrict__ rd_scale,
     float* __restrict__ scratch, uint8_t* __restrict__ pbuf, float* __restrict__ refbuf,
@@ -129,7 +170,11 @@ __device__ __forceinline__ void tile_body(
     // ---- DMA sources (global; null = nothing to issue)
     const uint8_t* __restrict__ src_nope, const uint16_t* __restrict__ src_rope, const float* __restrict__ src_scale,
     // ---- page geometry
-    const int tok0, const int L, const int L_row, const int L_min, const bool more_in_flight) {
+    const int tok0, const int L, const int L_row, const int L_min, const bool more_in_flight
+#ifdef FL_MLA_TIMING
+    , unsigned long long (&tacc)[8], unsigned long long& tlast
+#endif
+    ) {
   constexpr int NW = 2 * NRG;
   constexpr int kNopePerWave = kDmaNopePerTile / NW;
   constexpr int kRopePerWave = (FMT == 0 ? 8 : 4) / NW;
@@ -163,35 +208,39 @@ __device__ __forceinline__ void tile_body(
       *reinterpret_cast<uint4*>(wr + T * kDN + li * 16) = make_uint4(0, 0, 0, 0);
   }
 
-  // ---- per-token scale preprocessing: lanes 0..31 handle the 32 tokens of this wave's half ----
-  {
-    float ks = FMT == 0 ? rd_scale[32 * W + li] : ks_const;
-    if (tok0 + 32 * W + li >= L || !(ks > 0.f) || !(ks < 3.0e38f)) ks = 1.f;
-    if (lh == 0) {
-      scratch[li] = ks;
-      scratch[32 + li] = __builtin_amdgcn_logf(ks);
-      scratch[64 + li] = __builtin_amdgcn_rcpf(ks);
-    }
-  }
-
+  FL_T(0);   // prep (tail fill, scale scratch)
   // ---- A. S^T[32 tok x 32 rows] = K[32W + ..] · Q^T : all 20 operand reads in flight, then 12 back-to-back MFMAs ----
   v16f acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // V^T operands of the first PV tiles: issued inside the QK MFMA chain below
+  const uint8_t* vp = rd_nope + W * 256;   // d half -> 16 chunks of 16 B further along every token row
+  v8i va[8];
+  auto load_vt = [&](int jb) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint8_t* ap = vp + lc.vb[(jb & 3) | ((jb >> 2) << 2)] + (u & 1) * (16 * kDN) + (u >> 1) * (32 * kDN);
+      const v2i t2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)ap);
+      va[jb][2 * u] = t2[0];
+      va[jb][2 * u + 1] = t2[1];
+    }
+  };
   __builtin_amdgcn_sched_barrier(0);
   float4 ks4[4], lk4[4], ik4[4];
   {
-    const uint8_t* rp = rd_rope + W * (32 * (FMT == 0 ? kDR * 2 : kDR));
-    uint4 ra[4];
-#pragma unroll
-    for (int s = 0; s < (FMT == 0 ? 4 : 2); ++s) ra[s] = *reinterpret_cast<const uint4*>(rp + lc.rb[s]);
+    // rope + k-steps 0..3 were prefetched during the previous page's PV; fetch k-steps 4..7 now
     const uint8_t* kp = rd_nope + W * (32 * kDN);
     uint4 ka[8][2];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      ka[s][0] = *reinterpret_cast<const uint4*>(kp + lc.kb[0][s & 3] + (s >> 2) * 256);
-      ka[s][1] = *reinterpret_cast<const uint4*>(kp + lc.kb[1][s & 3] + (s >> 2) * 256);
+    for (int s = 0; s < 4; ++s) { ka[s][0] = pre.ka[s][0]; ka[s][1] = pre.ka[s][1]; }
+#pragma unroll
+    for (int s = 4; s < 8; ++s) {
+      ka[s][0] = *reinterpret_cast<const uint4*>(kp + lc.kb[0][s & 3] + 256);
+      ka[s][1] = *reinterpret_cast<const uint4*>(kp + lc.kb[1][s & 3] + 256);
     }
+    uint4 ra[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ra[s] = pre.ra[s];
     // per-token scale triples of this lane's 16 tokens (written above by this wave): queued behind the operand
     // reads, they land while the MFMAs run
 #pragma unroll
@@ -212,27 +261,22 @@ __device__ __forceinline__ void tile_body(
     for (int s = 0; s < 8; ++s)
       acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc, 0, 0, 0,
                                                             kUnitScale, 0, kUnitScale);
-    __builtin_amdgcn_sched_group_barrier(0x100, FMT == 0 ? 32 : 30, 0);   // DS reads: operands + 12 scale
-    __builtin_amdgcn_sched_group_barrier(0x008, FMT == 0 ? 12 : 9, 0);    // MFMA
+    // V^T operands of the first three PV tiles ride in the shadow of the MFMA chain (otherwise empty)
+    load_vt(0);
+    load_vt(1);
+    load_vt(2);
+    __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);                   // DS reads: 8 operand + 12 scale
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                    // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                    // tr8 reads of PV tile 0
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                    // PV tile 1
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                    // PV tile 2
+    __builtin_amdgcn_sched_group_barrier(0x008, FMT == 0 ? 5 : 2, 0);     // rest of the chain
   }
   __builtin_amdgcn_sched_barrier(0);
-  // V^T operands of the first PV tiles: issued now, they land under the softmax
-  const uint8_t* vp = rd_nope + W * 256;   // d half -> 16 chunks of 16 B further along every token row
-  v8i va[8];
-  auto load_vt = [&](int jb) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint8_t* ap = vp + lc.vb[(jb & 3) | ((jb >> 2) << 2)] + (u & 1) * (16 * kDN) + (u >> 1) * (32 * kDN);
-      const v2i t2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)ap);
-      va[jb][2 * u] = t2[0];
-      va[jb][2 * u + 1] = t2[1];
-    }
-  };
-  load_vt(0);
-  load_vt(1);
-  load_vt(2);
-  __builtin_amdgcn_sched_barrier(0);
 
+  FL_T(1);   // QK issue + V^T prefetch issue
   // ---- B. local online softmax on y = s*log2e + log2(k_scale[t]); tokens of lane: 32W + 8g + 4lh + e ----
   const bool need_mask = (tok0 + kPage > L_min);
   float tmax = -INFINITY;
@@ -280,8 +324,8 @@ __device__ __forceinline__ void tile_body(
       const float e1 = __builtin_amdgcn_exp2f(acc[g * 4 + 1] + moff);
       const float e2 = __builtin_amdgcn_exp2f(acc[g * 4 + 2] + moff);
       const float e3 = __builtin_amdgcn_exp2f(acc[g * 4 + 3] + moff);
-      st.l_run = fmaf(e0, ik4[g].x, st.l_run);
-      st.l_run = fmaf(e1, ik4[g].y, st.l_run);
+      st.l_run = fmaf(e0, ik4[g].x, st.l_run);   // unrounded sum: exact LSE (a rounded-sum LSE is off by up to 6 % on
+      st.l_run = fmaf(e1, ik4[g].y, st.l_run);   // peaked rows)
       st.l_run = fmaf(e2, ik4[g].z, st.l_run);
       st.l_run = fmaf(e3, ik4[g].w, st.l_run);
       int v = __builtin_amdgcn_cvt_pk_fp8_f32(e0, e1, 0, false);
@@ -300,6 +344,7 @@ __device__ __forceinline__ void tile_body(
     if (lh == 0) refbuf[(rg * 2 + W) * 32 + li] = st.m_w;
   }
 
+  FL_T(2);   // softmax + P publish
   // ---- C. page i+1 landed for every wave; P/refs visible ----
   if (more_in_flight) {
     if constexpr (NRG == 2)
@@ -312,34 +357,15 @@ __device__ __forceinline__ void tile_body(
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  // ---- D. refill: rope/scale of page i+2 (slot of page i), latent of page i+3 (slot of page i-1) ----
-#ifdef FL_EXP_NODMA   // experiment: compute only
-  if (false) {
-#else
-  if (src_rope != nullptr) {
-#endif
-#pragma unroll
-    for (int k = 0; k < kRopePerWave; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const uint8_t*>(src_rope) + lc.dr[k]),
-                                       (lds_ptr_t)(dma_rope + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
-    if constexpr (FMT == 0)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
-  }
-#ifdef FL_EXP_NODMA
-  if (false) {
-#else
-  if (src_nope != nullptr) {
-#endif
-#pragma unroll
-    for (int k = 0; k < kNopePerWave; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_nope + lc.dn[k]),
-                                       (lds_ptr_t)(dma_nope + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
-  }
-
+  FL_T(3);   // vmcnt + lgkmcnt + barrier
   // ---- E. B operand of the PV MFMA: bytes 0..15 = wave 0's P of this lane, 16..31 = wave 1's; both references ----
   const uint4 other_p = *reinterpret_cast<const uint4*>(pbuf + (rg * 2 + (1 - W)) * (64 * 16) + lane * 16);
   const float m0 = refbuf[(rg * 2 + 0) * 32 + li];
   const float m1 = refbuf[(rg * 2 + 1) * 32 + li];
+  // next page's raw scale (landed) -> registers now, prepared in the PV shadow
+  float ks_next = 1.f;
+  if (has_next) ks_next = FMT == 0 ? nx_scale[32 * W + li] : ks_const;
+  FL_T(4);
   const float mo_new = fmaxf(st.m_o, fmaxf(m0, m1));
   if (__any(mo_new > st.m_o)) {
     const float f = __builtin_amdgcn_exp2f(st.m_o - mo_new);   // exactly 1 where unchanged, 0 on the first page
@@ -352,19 +378,47 @@ __device__ __forceinline__ void tile_body(
   int sb = 127 + (int)((lh ? m1 : m0) - st.m_o);
   sb = sb < 0 ? 0 : sb;
   const v8i pb = W == 0 ? make_v8i(own_p, other_p) : make_v8i(other_p, own_p);
-
-  // ---- F. O^T[256W + .., 32 rows] += V^T · P^T, operand reads three tiles ahead of their MFMA ----
+  FL_T(5);   // O-reference update
+  // ---- F. O^T[256W + .., 32 rows] += V^T · P^T.  In the shadow of the 8 MFMAs (64 cycles each): the V^T reads three
+  //         tiles ahead, D. the LDS-DMA refill (rope/scale of page i+2 into the slots of page i, latent of page i+3 into
+  //         the slot of page i-1), the next page's scale triples and the first half of its QK operands. ----
+#ifdef FL_EXP_NODMA
+  const bool do_rs = false, do_n = false;
+#else
+  const bool do_rs = src_rope != nullptr, do_n = src_nope != nullptr;
+#endif
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
     if (jb + 3 < 8) load_vt(jb + 3);
     st.o[jb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[jb], pb, st.o[jb], 0, 0, 0, kUnitScale, 0, sb);
-  }
+    if (jb == 0 && do_rs) {
 #pragma unroll
-  for (int jb = 0; jb < 5; ++jb) {
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      for (int k = 0; k < kRopePerWave; ++k)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const uint8_t*>(src_rope) + lc.dr[k]),
+                                         (lds_ptr_t)(dma_rope + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
+      if constexpr (FMT == 0)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
+    }
+    if (do_n) {
+      constexpr int kPer = (kNopePerWave + 7) / 8;   // latent pieces issued behind each PV MFMA
+#pragma unroll
+      for (int k = jb * kPer; k < (jb + 1) * kPer && k < kNopePerWave; ++k)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_nope + lc.dn[k]),
+                                         (lds_ptr_t)(dma_nope + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
+    }
+    if (jb == 4 && has_next) {
+      // scale triples of the next page (this wave's scratch is free: its reads for this page completed before softmax)
+      float ks = ks_next;
+      if (tok0 + kPage + 32 * W + li >= L || !(ks > 0.f) || !(ks < 3.0e38f)) ks = 1.f;
+      if (lh == 0) {
+        scratch[li] = ks;
+        scratch[32 + li] = __builtin_amdgcn_logf(ks);
+        scratch[64 + li] = __builtin_amdgcn_rcpf(ks);
+      }
+    }
+    if (jb == 5 && has_next) qk_prefetch<FMT>(pre, lc, nx_nope, nx_rope, W);
   }
-  __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+  FL_T(6);   // PV issue
 }
 
 // Read-only inputs are separate `const __restrict__` kernel arguments so that hipcc proves them invariant: wave-
@@ -457,6 +511,11 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
       part = id / p.row_groups;
     }
   }
+#ifdef FL_MLA_STAGGER
+  // experiment: row group 1 starts late so that it finds row group 0's lines already in the XCD's L2
+  if (rgrp & 1)
+    for (int i = 0; i < FL_MLA_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   const int32_t* meta = g_meta + part * FL_MLA_META_W;
   int req = meta[0];
   int tile_b = meta[1];
@@ -468,6 +527,11 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
   const bool row_ok = row < p.rows;
 
   float* scratch = reinterpret_cast<float*>(smem + kOffScratch + wave * kScratchPerWave);
+#ifdef FL_MLA_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+  const unsigned long long tstart = tlast;
+#endif
 
   for (; req < p.bs; ++req, tile_b = 0, split_idx = 0) {
     if (req > end_req || (req == end_req && end_tile == 0)) break;
@@ -525,12 +589,20 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
     st.m_w = kNegRef;
     st.m_o = kNegRef;
 
-    // page id -> global sources of one page (wave-uniform)
-    auto page_of = [&](int t) {
-      int page = g_block_table[(long long)req * p.bt_stride + tile_b + t];
-      if (page < 0 || page >= p.num_pages) page = 0;
-      return (long long)page;
+    // page ids of a 64-page window live in ONE VGPR (lane j = page win_base + j); a lookup is a v_readlane, not an
+    // s_load whose lgkmcnt(0) would stall every page on scalar-memory latency.  The window is reloaded (one vector load,
+    // waited for inside the branch) only when the prefetch distance crosses its end.
+    int win_base = 0;
+    int pg_vec = 0;
+    auto load_window = [&](int base) {
+      win_base = base;
+      const int t = base + lane;
+      int pg = 0;
+      if (t < n) pg = g_block_table[(long long)req * p.bt_stride + tile_b + t];
+      pg_vec = (pg < 0 || pg >= p.num_pages) ? 0 : pg;   // (the use here keeps the load's wait inside this call)
     };
+    load_window(0);
+    auto page_of = [&](int t) { return (long long)__builtin_amdgcn_readlane(pg_vec, t - win_base); };
 
     // every wave finished with the LDS of the previous request (and the Q loads above are on the vmcnt queue: drain
     // them before counted waits start)
@@ -577,8 +649,15 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
       }
       __builtin_amdgcn_s_barrier();
     }
+    // page 0: scale triples + first half of the QK operands (later pages get them in the previous page's PV shadow)
+    QkPrefetch pre;
+    if (n > 0) {
+      scale_prep<FMT>(reinterpret_cast<const float*>(smem + kOffScale), scratch, ks_const, W, li, lh, tile_b * kPage, L);
+      qk_prefetch<FMT>(pre, lc, smem + kOffRing, smem + kOffRope, W);
+    }
 
     for (int i = 0; i < n; ++i) {
+      if (i + 3 >= win_base + 64 && i + 3 < n) load_window(i);   // pages i .. i+63
       const uint8_t* sn = nullptr;
       const uint16_t* sr = nullptr;
       const float* ss = nullptr;
@@ -593,14 +672,20 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
           ss = reinterpret_cast<const float*>(sr);   // unused (non-null)
         }
       }
-      tile_body<NRG, FMT>(st, lc, qn, qr, qr8, qs, ks_const, W, rg, wave,
+      tile_body<NRG, FMT>(st, pre, lc, qn, qr, qr8, qs, ks_const, W, rg, wave,
+                     smem + kOffRing + ((i + 1) & 3) * kSlotBytes, smem + kOffRope + ((i + 1) & 1) * kRopeBytes,
+                     reinterpret_cast<const float*>(smem + kOffScale + ((i + 1) & 1) * (kPage * 4)), i + 1 < n,
                      smem + kOffRing + (i & 3) * kSlotBytes, smem + kOffRope + (i & 1) * kRopeBytes,
                      reinterpret_cast<const float*>(smem + kOffScale + (i & 1) * (kPage * 4)), scratch,
                      smem + kOffPbuf + (i & 1) * kPbufPerParity,
                      reinterpret_cast<float*>(smem + kOffRef + (i & 1) * kRefPerParity),
                      smem + kOffRing + ((i + 3) & 3) * kSlotBytes, smem + kOffRope + (i & 1) * kRopeBytes,
                      reinterpret_cast<float*>(smem + kOffScale + (i & 1) * (kPage * 4)), sn, sr, ss,
-                     (tile_b + i) * kPage, L, L_row, L_min, i + 2 < n);
+                     (tile_b + i) * kPage, L, L_row, L_min, i + 2 < n
+#ifdef FL_MLA_TIMING
+                     , tacc, tlast
+#endif
+                     );
     }
 
     // ---- per-request epilogue: merge the two normalisers of the row group, normalise, store this wave's d half ----
@@ -665,7 +750,16 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
       }
     }
   }
+#ifdef FL_MLA_TIMING
+  if (g_dbg != nullptr && lc.lane == 0) {
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(g_dbg) + ((long long)blockIdx.x * 4 + wave) * 10;
+    for (int i = 0; i < 8; ++i) d[i] = tacc[i];
+    d[8] = __builtin_readcyclecounter() - tstart;
+    d[9] = tlast - tstart;
+  }
+#endif
 }
+
 
 // ---- split-KV combine: out[req,row,:] = sum_s w_s * o_accum[slot_s,row,:], w_s = softmax_s(lse_s) ----
 __global__ __launch_bounds__(256) void mla_combine_kernel(const Params p, const int32_t* __restrict__ g_num_splits) {
@@ -748,3 +842,9 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   FL_CHECK_LAUNCH("mla_combine_kernel");
   return FL_OK;
 }
+
+#if defined(FL_MLA_DEBUG) || defined(FL_MLA_TIMING)
+extern "C" int fl_mla_debug_set_buffer(int* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &dev_ptr, sizeof(dev_ptr));
+}
+#endif

@@ -10,6 +10,9 @@ bs = int(sys.argv[2]) if len(sys.argv) > 2 else bench.BS
 seq = int(sys.argv[3]) if len(sys.argv) > 3 else bench.SEQ
 dev = torch.device("cuda:0")
 wl = bench.build_workload(dev, layers, bs, seq, H, seed=1)
+if os.environ.get("SHARE_PAGES"):   # experiment: every request reads request 0's pages (100 % L2 hits after the first)
+    k = int(os.environ["SHARE_PAGES"])
+    wl["block_table"] = wl["block_table"][torch.arange(bs, device=dev) // k * k].contiguous()
 meta, ns = fm.get_mla_metadata(wl["seqlens"], H, 1)
 qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
 pages = wl["pages"]

@@ -1,0 +1,31 @@
+"""GPU box: per-phase cycle breakdown of the MLA decode kernel (FL_MLA_TIMING build)."""
+import os, sys, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["FLUENT_MI355_LIB"] = os.path.join(ROOT, "sglang-fluentllm_amd", "fluent_mi355", "libfluent_exp_TIMING.so")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sglang-fluentllm_amd"))
+import torch, bench, numpy as np
+import flash_mla_fp8 as fm
+from fluent_mi355 import lib
+dev = torch.device("cuda:0")
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+wl = bench.build_workload(dev, 1, bench.BS, bench.SEQ, H, seed=1)
+meta, ns = fm.get_mla_metadata(wl["seqlens"], H, 1)
+qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
+pages = wl["pages"]
+nblocks = meta.shape[0] * ((H + 63) // 64)
+dbg = torch.zeros(nblocks * 4 * 10 * 2, dtype=torch.int32, device=dev)
+lib.fl_mla_debug_set_buffer.argtypes = [ctypes.c_void_p]
+lib.fl_mla_debug_set_buffer(dbg.data_ptr())
+k_lora, k_scale, k_rope = wl["caches"][0]
+for _ in range(3):
+    fm.flash_mla_ckv_fp8_per_token(qn, qr, k_lora.view(pages, 64, 1, 512), k_rope.view(pages, 64, 1, 64), qs,
+                                   k_scale.view(pages, 64, 1, 1), wl["block_table"], wl["seqlens"], 512, meta, ns, bench.SCALE, True)
+torch.cuda.synchronize()
+d = dbg.cpu().numpy().view(np.uint64).reshape(nblocks * 4, 10).astype(np.float64)
+names = ["prep(scale scratch)", "QK issue+Vt prefetch", "softmax+P publish", "waits+barrier", "DMA issue", "P fetch+O ref", "PV issue", "-"]
+tiles = bench.SEQ // 64
+tot = d[:, 8].mean()
+print(f"H={H}: mean wave lifetime {tot:.0f} ticks; per page {tot/tiles:.0f} (s_memtime ticks, 100 MHz const clock -> x{2200/100:.0f} for ~cycles)")
+for i in range(7):
+    print(f"  {names[i]:24s} {d[:, i].mean()/tiles:8.1f} ticks/page  ({100*d[:, i].mean()/tot:5.1f} %)")
+print(f"  outside page loop        {(tot - d[:, :7].sum(1).mean())/tiles:8.1f} ticks/page-equivalent")
