@@ -2,6 +2,7 @@
 #include "fl_common.h"
 #include <mutex>
 #include <string>
+#include <cstdlib>
 
 static thread_local char g_err[512] = "";
 
@@ -13,6 +14,14 @@ void fl_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* fl_last_error(void) { return g_err; }
+
+bool fl_mla_use_x() {
+  static const bool on = [] {
+    const char* e = getenv("FLUENT_MLA_X");
+    return e != nullptr && e[0] == '1';
+  }();
+  return on;
+}
 extern "C" int fl_version(void) { return 100; }
 
 extern "C" int fl_device_cu_count(int device, int* cu_count) {

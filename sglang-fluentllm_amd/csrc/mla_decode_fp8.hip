@@ -35,16 +35,11 @@
 //     fp8 NaN patterns would poison the PV MFMA).
 //
 // Algorithmic bytes per (request, layer call): seq*644 (KV) + s_q*h_q*(644 + 1024) (Q in, O out) + 4*ceil(seq/64).
-#include "fl_common.h"
+#include "mla_decode_shared.h"
+
+using namespace fl_mla;
 
 namespace {
-
-constexpr int kPage = FL_MLA_PAGE;            // 64 tokens per page / tile
-constexpr int kDN = 512;                      // latent (nope) dims, fp8
-constexpr int kDR = 64;                       // rope dims, bf16
-constexpr int kSlotBytes = kPage * kDN;       // 32 KiB
-constexpr int kRopeBytes = kPage * kDR * 2;   // 8 KiB
-constexpr int kRingSlots = 4;
 
 // ---- LDS map (one __shared__ array) ----
 constexpr int kOffRing = 0;                                   // 4 x 32 KiB
@@ -59,26 +54,6 @@ constexpr int kRefPerParity = 2 * 2 * 32 * 4;
 constexpr int kLdsBytes = kOffRef + 2 * kRefPerParity;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kPShift = 8.0f;               // P' = 2^(y - m_W + 8) <= 256 < 448
-constexpr float kRefHeadroom = 2.0f;          // new reference = ceil(max) + 2: fewer reference moves
-constexpr float kNegRef = -16384.0f;          // "no reference yet" (finite, integer)
-constexpr int kUnitScale = 0x7F;              // E8M0 127 = 2^0
-constexpr int kDmaNopePerTile = 32;           // 1-KiB pieces per page
-
-struct Params {
-  int bs, s_q, h_q, rows, causal, num_parts, row_groups;
-  float scale_log2e;
-  const float* descale_q;   // FL_KV_FP8_576 only (device scalars, may be null = 1)
-  const float* descale_k;
-  long long num_pages;
-  long long bt_stride;
-  uint16_t* out;
-  float* lse;
-  float* o_accum;
-  float* lse_accum;
-};
-
 #if defined(FL_MLA_DEBUG) || defined(FL_MLA_TIMING)
 __device__ int* g_dbg = nullptr;   // debug builds only: set by fl_mla_debug_set_buffer
 #endif
@@ -87,21 +62,6 @@ __device__ int* g_dbg = nullptr;   // debug builds only: set by fl_mla_debug_set
 #else
 #define FL_T(i) do { } while (0)
 #endif
-
-typedef float float2v __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-__device__ __forceinline__ v8bf as_bf8(uint4 v) {
-  union { uint4 u; v8bf b; } x;
-  x.u = v;
-  return x.b;
-}
-__device__ __forceinline__ v8i make_v8i(uint4 a, uint4 b) {
-  v8i r;
-  r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
-  return r;
-}
 
 // Per-lane constants of the LDS access patterns (computed once per kernel).
 struct LaneConst {
@@ -802,6 +762,15 @@ __global__ __launch_bounds__(256) void mla_combine_kernel(const Params p, const 
 
 }  // namespace
 
+int fl_mla_launch_combine(const Params& p, const int32_t* num_splits, hipStream_t stream) {
+  const long long waves = (long long)p.bs * p.rows;
+  mla_combine_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(p, num_splits);
+  FL_CHECK_LAUNCH("mla_combine_kernel");
+  return FL_OK;
+}
+
+int fl_mla_decode_fp8_x_impl(const FlMlaDecodeArgs* a, const Params& p, hipStream_t stream);   // mla_decode_fp8_x.hip
+
 int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   const bool per_token = a->kv_format == FL_KV_FP8_PER_TOKEN;
   FL_CHECK_ARG(a->d_nope == kDN && a->d_rope == kDR, "fl_mla_decode: only d_nope=512,d_rope=64 (got %d,%d)",
@@ -821,8 +790,14 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   p.descale_q = a->descale_q; p.descale_k = a->descale_k;
   p.num_pages = a->num_pages; p.bt_stride = a->block_table_stride;
   p.out = (uint16_t*)a->out; p.lse = a->lse; p.o_accum = a->o_accum; p.lse_accum = a->lse_accum;
+  // rows > 64 (e.g. TP1, H=128), opt-in (FLUENT_MLA_X=1: measured slower so far): 128-row workgroups
+  // that ingest every KV byte once (mla_decode_fp8_x.hip).
   // rows <= 32 (e.g. the TP8 shard, H=16): one row group per workgroup (2 waves); otherwise 2 row groups (4 waves).
-  // FL_MLA_ROWS_PER_WG (= 64) only sizes the scheduler's part count; both shapes give 1 row group for rows <= 32.
+  // fl_mla_num_parts sizes the scheduler's part count with the same rule.
+  if (fl_mla_use_x() && p.rows > 64) {
+    p.row_groups = (p.rows + 127) / 128;
+    return fl_mla_decode_fp8_x_impl(a, p, stream);
+  }
   const int nrg = p.rows > 32 ? 2 : 1;
   p.row_groups = (p.rows + 32 * nrg - 1) / (32 * nrg);
   const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(128 * nrg);
@@ -837,10 +812,7 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   }
 #undef FL_LAUNCH
   FL_CHECK_LAUNCH("mla_decode_fp8_kernel");
-  const long long waves = (long long)p.bs * p.rows;
-  mla_combine_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(p, a->num_splits);
-  FL_CHECK_LAUNCH("mla_combine_kernel");
-  return FL_OK;
+  return fl_mla_launch_combine(p, a->num_splits, stream);
 }
 
 #if defined(FL_MLA_DEBUG) || defined(FL_MLA_TIMING)

@@ -1,0 +1,702 @@
+// K1/K2 for more than 64 query rows per request (TP1: s_q*H = 128, 256, ...) — paged MLA decode over the FP8 latent
+// KV cache, gfx950 (MI355X) only.  Same math, data formats and call sites as mla_decode_fp8.hip
+// (flash_mla_fp8.flash_mla_ckv_fp8_per_token, flashmla_backend.py:208-222 / :127-142; flash_mla_with_kvcache :227-239).
+//
+// Why a second mapping: with 64-row workgroups a 128-head request needs two workgroups that each pull every KV page
+// through their own LDS (measured: the per-CU LDS-DMA ingest, not HBM, then bounds the kernel).  Here ONE workgroup of
+// 4 waves owns 128 query rows and every KV byte enters one LDS once; the scheduler splits the token axis instead
+// (fl_mla_num_parts = CUs / ceil(rows/128)) and the split partials are merged by the combine kernel.
+//
+//   * wave w owns query rows [32w, 32w+32) for ALL 64 tokens of a page and ALL 512 latent dims:
+//       S^T block b (tokens 32b..32b+31) = K_b · Q^T : 8 x v_mfma_scale_f32_32x32x64_f8f6f4 (+ 4 x 32x32x16 bf16 rope)
+//       O^T[512 x 32 rows] += V^T · P^T              : 16 x v_mfma_scale_f32_32x32x64_f8f6f4, O = all 256 AGPRs
+//     so P never leaves the lane that produced it: bytes 0..15 of the PV B operand are the lane's block-0 weights,
+//     bytes 16..31 its block-1 weights (MX block b takes its E8M0 scale from lane n+32b: the two blocks keep
+//     INDEPENDENT integer softmax references m_b, reconciled for free by the block scales 2^(m_b - M)).  No P exchange,
+//     no cross-wave reduction; the only workgroup barrier per page certifies the LDS ring.
+//   * software pipeline inside one wave (one wave per SIMD, in-order issue): iteration i runs
+//       QK block 0 of page i      ||  softmax of block 1 of page i-1
+//       PV of page i-1 (16 MFMA)  ||  softmax of block 0 of page i
+//       QK block 1 of page i
+//     so the VALU/transcendental work of a block always sits in the shadow of independent MFMAs.
+//   * LDS: 4-slot ring of 32 KiB latent pages (page i-1 is still read for V^T while page i is read for K and pages
+//     i+1, i+2 are landing), 3-slot rings for rope and raw scales, per-wave scale-triple scratch (2 parities).
+//     HBM -> LDS only by global_load_lds; swizzles, operand layouts and tr8 V^T reads as in mla_decode_fp8.hip.
+#include "mla_decode_shared.h"
+
+using namespace fl_mla;
+
+namespace {
+
+constexpr int kNW = 4;                                          // waves per workgroup, 32 query rows each
+constexpr int kRopeSlots = 3;
+constexpr int kOffRing = 0;                                     // 4 x 32 KiB
+constexpr int kOffRope = kOffRing + kRingSlots * kSlotBytes;    // 3 x 8 KiB
+constexpr int kOffScale = kOffRope + kRopeSlots * kRopeBytes;   // 3 x 64 f32 raw k_scale
+constexpr int kScratchPerWave = 3 * kPage * 4;                  // {ks, log2 ks, 1/ks} x 64 tokens
+constexpr int kOffScratch = kOffScale + kRopeSlots * kPage * 4; // [wave 4]
+constexpr int kOffFlag = kOffScratch + kNW * kScratchPerWave;    // 4 ints: redo votes
+constexpr int kLdsBytes = kOffFlag + 16;
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+
+constexpr int kNopePerWave = kDmaNopePerTile / kNW;             // 8 LDS-DMA pieces of 1 KiB per wave per page
+constexpr float kMaxUp = 100.f;                                 // largest block-scale exponent above the O reference
+#ifndef FL_X_OVERLAP
+#define FL_X_OVERLAP true    // softmax of block 0 inside the QK MFMA chain of block 1 (register pressure!)
+#endif
+
+#ifdef FL_MLA_TIMING
+__device__ int* g_dbg_x = nullptr;   // debug builds only: set by fl_mla_debug_set_buffer_x
+#define FL_T(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); tacc[i] += t__ - tlast; tlast = t__; } while (0)
+#define FL_T_PARAMS , unsigned long long (&tacc)[8], unsigned long long& tlast
+#define FL_T_ARGS , tacc, tlast
+#else
+#define FL_T(i) do { } while (0)
+#define FL_T_PARAMS
+#define FL_T_ARGS
+#endif
+
+struct LaneConst {
+  int lane, li, lh;
+  int kb[4];       // K operand: byte offset inside a slot for k-step s&3, first 16 B (second: ^16); + (s>>2)*256; + b*16384
+  int rb0;         // rope operand, k-step 0 (k-step s: ^ (s << 5); FMT 1 second half: ^16)
+  int vb0;         // V^T tr8 source of tile jb = 0 (tile jb: ^ ((jb&3) << 4) ^ ((jb>>2) << 7)); + u immediates; + dh*256
+  unsigned dn_row; // latent DMA: byte offset of this lane's token row of piece 0 of this wave
+  unsigned dn_x;   // ... and its swizzled 16-B chunk (piece k: ^ (k << 5))
+  unsigned dr[2];
+};
+
+struct ReqState {
+  v16f o[16];            // O^T: tile dh*8 + jb
+  float l[2], lq[2];     // exact / rounded-weight normalisers per block, relative to mw[b]
+  float mw[2];           // integer softmax references per block
+  float mo;              // reference of O (fixed once set)
+  int redo;              // a block reference outran mo by more than kMaxUp: repeat the request with mo preset
+};
+
+// ---- hand-scheduled building blocks.  hipcc's scheduler, left alone with a whole pipeline step, hoists every LDS
+// operand read to the top (hundreds of live registers, spills).  A step is therefore written as a sequence of SLOTS —
+// one MFMA + a bounded chunk of the overlapped softmax + the operand reads of two slots ahead — fenced by
+// sched_barrier(0), i.e. the software pipeline is fixed in the source. ----
+#define FL_SLOT_END() __builtin_amdgcn_sched_barrier(0)
+
+// K operand (A side) of QK k-step s of block b: token 32b + li, 32 B at d = 64s + 32lh
+struct KOp { uint4 lo, hi; };
+__device__ __forceinline__ KOp k_load(const LaneConst& lc, const uint8_t* __restrict__ kp, const int s) {
+  KOp r;
+  r.lo = *reinterpret_cast<const uint4*>(kp + lc.kb[s & 3] + (s >> 2) * 256);
+  r.hi = *reinterpret_cast<const uint4*>(kp + (lc.kb[s & 3] ^ 16) + (s >> 2) * 256);
+  return r;
+}
+
+// V^T operand (A side) of PV tile t = dh*8 + jb: ds_read_b64_tr_b8 x 4
+__device__ __forceinline__ v8i vt_load(const LaneConst& lc, const uint8_t* __restrict__ v_nope, const int t) {
+  const int dh = t >> 3, jb = t & 7;
+  const uint8_t* vp = v_nope + dh * 256 + (lc.vb0 ^ (((jb & 3) << 4) | ((jb >> 2) << 7)));
+  v8i va;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint8_t* ap = vp + (u & 1) * (16 * kDN) + (u >> 1) * (32 * kDN);
+    const v2i t2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)ap);
+    va[2 * u] = t2[0];
+    va[2 * u + 1] = t2[1];
+  }
+  return va;
+}
+
+// QK MFMAs with the S accumulator pinned to the VGPR half.  This file is compiled in hipcc's default MFMA form for one
+// wave per SIMD (accumulators in AGPRs): exactly right for the 16 O tiles, which fill all 256 AGPRs, and wrong for S,
+// which the softmax reads with VALU instructions — there is no per-instruction switch (and -amdgpu-mfma-vgpr-form=1
+// moves O through VGPRs around every PV MFMA).  Hence inline asm with "v" constraints; the XDL-write -> VALU-read
+// hazard that the compiler cannot see through inline asm is covered by FL_MFMA_DRAIN() before S is first read.
+__device__ __forceinline__ v4i as_v4i(const uint4 a) { return v4i{(int)a.x, (int)a.y, (int)a.z, (int)a.w}; }
+__device__ __forceinline__ v4i as_v4i(const v8bf b) {
+  union { v8bf b; v4i i; } x;
+  x.b = b;
+  return x.i;
+}
+__device__ __forceinline__ void mfma_rope_first(v16f& acc, const uint4 a, const v8bf b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(as_v4i(a)), "v"(as_v4i(b)));
+}
+__device__ __forceinline__ void mfma_rope(v16f& acc, const uint4 a, const v8bf b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(as_v4i(a)), "v"(as_v4i(b)));
+}
+__device__ __forceinline__ void mfma_fp8_first(v16f& acc, const v8i a, const v8i b) {
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]"
+               : "=&v"(acc)
+               : "v"(a), "v"(b), "v"(kUnitScale));
+}
+__device__ __forceinline__ void mfma_fp8(v16f& acc, const v8i a, const v8i b) {
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+               : "+v"(acc)
+               : "v"(a), "v"(b), "v"(kUnitScale));
+}
+#define FL_MFMA_DRAIN() asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory")
+
+// Online softmax of one S^T block on y = s*log2e + log2(k_scale[t]) (folds the per-token V scale into P), in chunks.
+// Lane (li, lh) holds query row li and tokens 32b + 8g + 4lh + e.  Result: 16 fp8 weights P' = 2^(y - m + 8).
+struct Soft {
+  v16f y;
+  float4 a4[4], b4[2];   // a4[g]: k_scale of group g, later 1/k_scale; b4[g&1]: log2 k_scale of group g
+  float tmax, moff;
+  int pk[4];
+};
+constexpr int kSoftChunks = 10;
+__device__ __forceinline__ void sm_load_kl(Soft& c, const float* __restrict__ scr, const int g, const int b,
+                                           const int lh) {
+  const int tb = 32 * b + g * 8 + lh * 4;
+  c.a4[g] = *reinterpret_cast<const float4*>(scr + tb);
+  c.b4[g & 1] = *reinterpret_cast<const float4*>(scr + kPage + tb);
+}
+__device__ __forceinline__ void sm_scale(Soft& c, const int g, const float qs, const int b, const int lh, const int tok0,
+                                         const int L_row, const bool need_mask) {
+  const float ksv[4] = {c.a4[g].x, c.a4[g].y, c.a4[g].z, c.a4[g].w};
+  const float lkv[4] = {c.b4[g & 1].x, c.b4[g & 1].y, c.b4[g & 1].z, c.b4[g & 1].w};
+  float y[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) y[e] = fmaf(c.y[g * 4 + e] * qs, ksv[e], lkv[e]);
+  if (need_mask) {   // wave-uniform: only the last page(s) of a sequence
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (tok0 + 32 * b + g * 8 + lh * 4 + e >= L_row) y[e] = -INFINITY;
+      if (!(y[e] == y[e])) y[e] = -INFINITY;   // NaN can only come from garbage beyond the row's limit
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c.y[g * 4 + e] = y[e];
+  c.tmax = fmaxf(fmaxf(c.tmax, fmaxf(y[0], y[1])), fmaxf(y[2], y[3]));
+}
+__device__ __forceinline__ void sm_ref(Soft& c, const float* __restrict__ scr, const int b, const int lh, float& m_w,
+                                       float& l_run, float& lq_run) {
+  const float tmax = fmaxf(c.tmax, __shfl_xor(c.tmax, 32));
+  const float m_new = tmax > m_w ? ceilf(tmax) + kRefHeadroom : m_w;
+  const float f = __builtin_amdgcn_exp2f(m_w - m_new);   // exactly 1 when the reference did not move
+  l_run *= f;
+  lq_run *= f;
+  m_w = m_new;
+  c.moff = kPShift - m_new;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    c.a4[g] = *reinterpret_cast<const float4*>(scr + 2 * kPage + 32 * b + g * 8 + lh * 4);
+}
+__device__ __forceinline__ void sm_exp(Soft& c, const int g, float& l_run, float& lq_run) {
+  const float e0 = __builtin_amdgcn_exp2f(c.y[g * 4 + 0] + c.moff);
+  const float e1 = __builtin_amdgcn_exp2f(c.y[g * 4 + 1] + c.moff);
+  const float e2 = __builtin_amdgcn_exp2f(c.y[g * 4 + 2] + c.moff);
+  const float e3 = __builtin_amdgcn_exp2f(c.y[g * 4 + 3] + c.moff);
+  l_run = fmaf(e0, c.a4[g].x, l_run);   // unrounded sum: exact LSE
+  l_run = fmaf(e1, c.a4[g].y, l_run);
+  l_run = fmaf(e2, c.a4[g].z, l_run);
+  l_run = fmaf(e3, c.a4[g].w, l_run);
+  const int v = __builtin_amdgcn_cvt_pk_fp8_f32(e0, e1, 0, false);
+  c.pk[g] = __builtin_amdgcn_cvt_pk_fp8_f32(e2, e3, v, true);
+  // the ROUNDED weights normalise O (numerator and denominator use the same weights: they sum to exactly 1)
+  const float2v d01 = __builtin_amdgcn_cvt_pk_f32_fp8(c.pk[g], false);
+  const float2v d23 = __builtin_amdgcn_cvt_pk_f32_fp8(c.pk[g], true);
+  lq_run = fmaf(d01[0], c.a4[g].x, lq_run);
+  lq_run = fmaf(d01[1], c.a4[g].y, lq_run);
+  lq_run = fmaf(d23[0], c.a4[g].z, lq_run);
+  lq_run = fmaf(d23[1], c.a4[g].w, lq_run);
+}
+// chunk k (0..9) of a block's softmax: 0 = scales of group 0; 1..4 = scale + max of group k-1 (and the scales of
+// group k); 5 = reference (and the 1/k_scale loads); 6..9 = exp groups
+__device__ __forceinline__ void sm_chunk(Soft& c, const int k, const float* __restrict__ scr, const int b, const int lh,
+                                         const float qs, const int tok0, const int L_row, const bool need_mask,
+                                         float& m_w, float& l_run, float& lq_run) {
+  if (k == 0) {
+    c.tmax = -INFINITY;
+    sm_load_kl(c, scr, 0, b, lh);
+  } else if (k <= 4) {
+    if (k < 4) sm_load_kl(c, scr, k, b, lh);
+    sm_scale(c, k - 1, qs, b, lh, tok0, L_row, need_mask);
+  } else if (k == 5) {
+    sm_ref(c, scr, b, lh, m_w, l_run, lq_run);
+  } else if (k < kSoftChunks) {
+    sm_exp(c, k - 6, l_run, lq_run);
+  }
+}
+
+// QK of block b with the softmax chunks of ANOTHER block interleaved (SOFT = false: none).  12 slots (FMT 0).
+template <int FMT, bool SOFT>
+__device__ __forceinline__ v16f qk_stage(const LaneConst& lc, const uint8_t* __restrict__ k_nope,
+                                         const uint8_t* __restrict__ k_rope, const int b, const v8i (&qn)[8],
+                                         const v8bf (&qr)[4], const v8i qr8, Soft& c, const float* __restrict__ scr,
+                                         const int sb_, const int lh, const float qs, const int tok0, const int L_row,
+                                         const bool need_mask, float& m_w, float& l_run, float& lq_run) {
+  const uint8_t* kp = k_nope + b * (32 * kDN);
+  const uint8_t* rp = k_rope + b * (32 * (FMT == 0 ? kDR * 2 : kDR));
+  uint4 ra[4];
+  ra[0] = *reinterpret_cast<const uint4*>(rp + lc.rb0);
+  ra[1] = *reinterpret_cast<const uint4*>(rp + (lc.rb0 ^ (FMT == 0 ? 32 : 16)));
+  KOp ka[3];
+  ka[0] = k_load(lc, kp, 0);
+  if constexpr (SOFT) sm_chunk(c, 0, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
+  FL_SLOT_END();
+  v16f acc;
+  int chunk = 1;
+  if constexpr (FMT == 0) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < 2) ra[s + 2] = *reinterpret_cast<const uint4*>(rp + (lc.rb0 ^ ((s + 2) << 5)));
+      if (s == 2) ka[1] = k_load(lc, kp, 1);
+      if (s == 0) mfma_rope_first(acc, ra[s], qr[s]);
+      else mfma_rope(acc, ra[s], qr[s]);
+      if (SOFT && (s & 1)) { sm_chunk(c, chunk, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run); ++chunk; }
+      FL_SLOT_END();
+    }
+  } else {
+    ka[1] = k_load(lc, kp, 1);
+    mfma_fp8_first(acc, make_v8i(ra[0], ra[1]), qr8);
+    if constexpr (SOFT) {
+      sm_chunk(c, 1, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
+      sm_chunk(c, 2, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
+      chunk = 3;
+    }
+    FL_SLOT_END();
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (s + 2 < 8) ka[(s + 2) % 3] = k_load(lc, kp, s + 2);
+    mfma_fp8(acc, make_v8i(ka[s % 3].lo, ka[s % 3].hi), qn[s]);
+    if (SOFT && chunk < kSoftChunks) {
+      sm_chunk(c, chunk, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
+      ++chunk;
+    }
+    FL_SLOT_END();
+  }
+  FL_MFMA_DRAIN();   // acc is read by VALU instructions next
+  return acc;
+}
+
+// Copy of the lane constants that the optimiser cannot see through: everything derived from it stays where it is used
+// instead of being hoisted (LICM) into dozens of long-lived registers.
+__device__ __forceinline__ LaneConst opaque(const LaneConst& in) {
+  LaneConst lc = in;
+  asm volatile("" : "+v"(lc.lane), "+v"(lc.li), "+v"(lc.lh), "+v"(lc.kb[0]), "+v"(lc.kb[1]), "+v"(lc.kb[2]),
+               "+v"(lc.kb[3]), "+v"(lc.rb0), "+v"(lc.vb0), "+v"(lc.dn_row), "+v"(lc.dn_x), "+v"(lc.dr[0]),
+               "+v"(lc.dr[1]));
+  return lc;
+}
+
+// byte offset inside the page of this lane's 16 B of latent piece k of this wave (2 token rows of 512 B per piece,
+// chunk c of token T stored at chunk c ^ (T & 15))
+template <int FMT>
+__device__ __forceinline__ unsigned dn_off(const LaneConst& lc, const int k) {
+  constexpr unsigned kTokBytes = FMT == 0 ? kDN : kDN + kDR;
+  return lc.dn_row + (unsigned)k * 2u * kTokBytes + (lc.dn_x ^ ((unsigned)k << 5));
+}
+
+// One page of one request for one wave.  All LDS regions are distinct __restrict__ parameters of ONE inlined function
+// (see mla_decode_fp8.hip: otherwise hipcc drains the LDS-DMA queue with vmcnt(0) before every ds_read).
+template <int FMT>
+__device__ __forceinline__ void page_step(
+    ReqState& st, const LaneConst& lc_in, const v8i (&qn)[8], const v8bf (&qr)[4], const v8i qr8, const float qs,
+    const float ks_const, const int wave,
+    // ---- page i: latent slot, rope slot, raw scales; wave-private triple scratch
+    const uint8_t* __restrict__ k_nope, const uint8_t* __restrict__ k_rope, const float* __restrict__ k_scale_raw,
+    float* __restrict__ scr,
+    // ---- LDS regions filled by the DMA issued in this call (never read in this call)
+    uint8_t* __restrict__ dma_nope, uint8_t* __restrict__ dma_rope, float* __restrict__ dma_scale,
+    const uint8_t* __restrict__ src_nope, const uint8_t* __restrict__ src_rope, const float* __restrict__ src_scale,
+    // ---- geometry
+    const int tok0, const int L, const int L_row, const bool need_mask, const int pages_ahead FL_T_PARAMS) {
+  constexpr int kRopePerWave = (FMT == 0 ? 8 : 4) / kNW;
+  // The lane constants are made opaque per step: otherwise LICM hoists every derived LDS/global address (dozens of
+  // loop-invariant registers) out of the page loop and the step no longer fits next to the 256-register O accumulator.
+  const LaneConst lc = opaque(lc_in);
+  const int lane = lc.lane, li = lc.li, lh = lc.lh;
+
+  // ---- page i landed for every wave (issue order per step: rope, scale, latent; see the kernel's page loop); every
+  //      wave is done with page i-1, whose slots are refilled below ----
+  if (pages_ahead >= 2) {
+    if constexpr (FMT == 0) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");   // latent i+1 | rope, scale i+1 | latent i+2
+    else asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+  } else if (pages_ahead == 1) {
+    if constexpr (FMT == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  FL_T(0);   // wait for page i + barrier
+  if (src_rope != nullptr) {
+#pragma unroll
+    for (int k = 0; k < kRopePerWave; ++k)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_rope + lc.dr[k]),
+                                       (lds_ptr_t)(dma_rope + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
+    if constexpr (FMT == 0)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
+  }
+  if (src_nope != nullptr) {
+#pragma unroll
+    for (int k = 0; k < kNopePerWave; ++k)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_nope + dn_off<FMT>(lc, k)),
+                                       (lds_ptr_t)(dma_nope + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
+  }
+
+  {
+    // scale triples of the page (lane = token), wave-private scratch
+    float ks = FMT == 0 ? k_scale_raw[lane] : ks_const;
+    if (tok0 + lane >= L || !(ks > 0.f) || !(ks < 3.0e38f)) ks = 1.f;
+    scr[lane] = ks;
+    scr[kPage + lane] = __builtin_amdgcn_logf(ks);
+    scr[2 * kPage + lane] = __builtin_amdgcn_rcpf(ks);
+    {
+      // tail of the sequence: zero the rows past the end (P' is exactly 0 there, but 0*NaN would poison the PV MFMA)
+      if (tok0 + kPage > L) {
+        const int nvalid = L - tok0;
+        uint8_t* wr = const_cast<uint8_t*>(k_nope);
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (int T = nvalid + lh; T < kPage; T += 2)
+          *reinterpret_cast<uint4*>(wr + T * kDN + li * 16) = make_uint4(0, 0, 0, 0);
+      }
+    }
+  }
+  FL_SLOT_END();
+  FL_T(1);   // DMA issue + scale triples
+
+  // ---- A. S^T blocks 0 and 1; the softmax of block 0 rides in the MFMA shadow of block 1 ----
+  Soft c0, c1;
+  c0.y = qk_stage<FMT, false>(lc, k_nope, k_rope, 0, qn, qr, qr8, c1, scr, 0, lh, qs, tok0, L_row, need_mask,
+                             st.mw[0], st.l[0], st.lq[0]);
+  FL_SLOT_END();
+  c1.y = qk_stage<FMT, FL_X_OVERLAP>(lc, k_nope, k_rope, 1, qn, qr, qr8, c0, scr, 0, lh, qs, tok0, L_row, need_mask,
+                                     st.mw[0], st.l[0], st.lq[0]);
+  FL_SLOT_END();
+  FL_T(2);   // QK
+  // ---- B. the rest of the softmax ----
+  if constexpr (!FL_X_OVERLAP) {
+#pragma unroll
+    for (int k = 0; k < kSoftChunks; ++k) sm_chunk(c0, k, scr, 0, lh, qs, tok0, L_row, need_mask, st.mw[0], st.l[0], st.lq[0]);
+    FL_SLOT_END();
+  }
+#pragma unroll
+  for (int k = 0; k < kSoftChunks; ++k) sm_chunk(c1, k, scr, 1, lh, qs, tok0, L_row, need_mask, st.mw[1], st.l[1], st.lq[1]);
+  FL_SLOT_END();
+  FL_T(3);   // softmax
+
+  // ---- C. O^T += V^T · P^T.  The reference of O is fixed when a row sees its first valid token and NEVER moves in
+  //      this pass: later blocks with a larger reference m_b enter with an E8M0 block scale 2^(m_b - mo) > 1 (exact;
+  //      fp32 O has the range).  Only a reference more than kMaxUp above mo (a logit that beats the row's first-page
+  //      maximum by > 69 nats) cannot be represented: it raises st.redo and the kernel repeats the request with mo
+  //      preset to the final reference.  So O is touched by nothing but the MFMA in the page loop. ----
+  const float mw_max = fmaxf(st.mw[0], st.mw[1]);
+  st.mo = st.mo > kNegRef ? st.mo : mw_max;
+  st.redo |= (mw_max - st.mo > kMaxUp) ? 1 : 0;
+  int sb = 127 + (int)fminf((lh ? st.mw[1] : st.mw[0]) - st.mo, kMaxUp);
+  sb = sb < 0 ? 0 : sb;
+  const v8i pb = make_v8i(make_uint4(c0.pk[0], c0.pk[1], c0.pk[2], c0.pk[3]),
+                          make_uint4(c1.pk[0], c1.pk[1], c1.pk[2], c1.pk[3]));
+  v8i va[3];
+  va[0] = vt_load(lc, k_nope, 0);
+  va[1] = vt_load(lc, k_nope, 1);
+  FL_SLOT_END();
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    if (t + 2 < 16) va[(t + 2) % 3] = vt_load(lc, k_nope, t + 2);
+    st.o[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[t % 3], pb, st.o[t], 0, 0, 0, kUnitScale, 0, sb);
+    FL_SLOT_END();
+  }
+  FL_T(4);   // PV issue
+}
+
+template <int FMT>
+__global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
+    const Params p, const int32_t* __restrict__ g_block_table, const int32_t* __restrict__ g_seqlens,
+    const int32_t* __restrict__ g_meta, const int32_t* __restrict__ g_num_splits,
+    const uint8_t* __restrict__ g_k_nope, const uint16_t* __restrict__ g_k_rope, const float* __restrict__ g_k_scale,
+    const uint8_t* __restrict__ g_q_nope, const uint16_t* __restrict__ g_q_rope, const float* __restrict__ g_q_scale) {
+  constexpr int kTokBytes = FMT == 0 ? kDN : kDN + kDR;    // bytes per token row of the latent tensor in HBM
+  constexpr int kRopeTok = FMT == 0 ? kDR * 2 : kDR;        // bytes per token of rope (bf16 / fp8)
+  constexpr int kRopePerWave = (FMT == 0 ? 8 : 4) / kNW;
+  __shared__ __attribute__((aligned(16))) uint8_t smem[kLdsBytes];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  LaneConst lc0;
+  lc0.lane = tid & 63;
+  lc0.li = lc0.lane & 31;
+  lc0.lh = lc0.lane >> 5;
+  lc0.dr[0] = lc0.dr[1] = 0;
+  {
+    // operand layouts and swizzles: identical to mla_decode_fp8.hip (derivations there)
+    LaneConst& lc = lc0;
+    const int li = lc.li, lh = lc.lh, lane = lc.lane;
+    const int kx = li & 15;
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2)
+      lc.kb[k2] = li * kDN + (((((k2 ^ (kx >> 2)) << 2) | ((2 * lh) ^ (kx & 3))) << 4));
+    if constexpr (FMT == 0) lc.rb0 = li * (kDR * 2) + (((lh ^ ((li >> 1) & 7))) << 4);
+    else lc.rb0 = li * kDR + ((((2 * lh) ^ ((li >> 2) & 3))) << 4);
+    const int s16 = lane & 15;
+    const int gi = (lane >> 4) & 1;
+    const int tj = s16 >> 1;
+    const int tok_in8 = (tj & 3) + ((tj >> 2) << 3);
+    const int vrow = 4 * lh + tok_in8;
+    lc.vb0 = vrow * kDN + ((((gi << 2)) ^ (vrow & 15)) << 4) + (s16 & 1) * 8;
+    // latent DMA piece k of this wave: token row T = (wave*8 + k)*2 + lh, chunk li stored from source chunk li ^ (T&15)
+    lc.dn_row = (unsigned)((wave * kNopePerWave * 2 + lh) * kTokBytes);
+    lc.dn_x = (unsigned)((li ^ lh) << 4);
+#pragma unroll
+    for (int k = 0; k < kRopePerWave; ++k) {   // BYTE offsets inside the page's rope block
+      if constexpr (FMT == 0) {
+        const int T = (wave * kRopePerWave + k) * 8 + (lane >> 3);   // 8 token rows of 128 B per piece
+        lc.dr[k] = (unsigned)(T * 128 + (((lane & 7) ^ ((T >> 1) & 7)) << 4));
+      } else {
+        const int T = (wave * kRopePerWave + k) * 16 + (lane >> 2);  // 16 token rows of 64 B per piece
+        lc.dr[k] = (unsigned)(T * kTokBytes + kDN + (((lane & 3) ^ ((T >> 2) & 3)) << 4));
+      }
+    }
+  }
+  const int lane = lc0.lane, li = lc0.li, lh = lc0.lh;
+
+  // ---- workgroup -> (part, row group) ----
+  const int rgrp = blockIdx.x % p.row_groups;
+  const int part = blockIdx.x / p.row_groups;
+  const int32_t* meta = g_meta + part * FL_MLA_META_W;
+  int req = meta[0];
+  int tile_b = meta[1];
+  const int end_req = meta[2];
+  const int end_tile = meta[3];
+  int split_idx = meta[4];
+
+#ifdef FL_MLA_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+  const unsigned long long tstart = tlast;
+#endif
+  const int row = rgrp * (32 * kNW) + wave * 32 + li;   // query row of this lane
+  const bool row_ok = row < p.rows;
+
+  for (; req < p.bs; ++req, tile_b = 0, split_idx = 0) {
+    if (req > end_req || (req == end_req && end_tile == 0)) break;
+    const int L = g_seqlens[req];
+    const int nt = L > 0 ? (L + kPage - 1) / kPage : 0;
+    int tile_e = req < end_req ? nt : (end_tile < nt ? end_tile : nt);
+    if (tile_e < tile_b) tile_e = tile_b;
+    const int n = tile_e - tile_b;
+    const int split_base = g_num_splits[req];
+    const bool is_split = (g_num_splits[req + 1] - split_base) > 1;
+
+    // ---- Q fragments (B operands), once per request ----
+    const long long qrow = (long long)req * p.rows + row;
+    v8i qn[8];
+    v8bf qr[4];
+    v8i qr8 = v8i{0, 0, 0, 0, 0, 0, 0, 0};
+    float qs = 0.f;
+    float ks_const = 1.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qr[s] = as_bf8(make_uint4(0, 0, 0, 0));
+    if constexpr (FMT == 1) ks_const = p.descale_k ? *p.descale_k : 1.f;
+    if (row_ok) {
+      const uint8_t* qp = g_q_nope + qrow * kTokBytes + lh * 32;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const uint4 a = *reinterpret_cast<const uint4*>(qp + s * 64);
+        const uint4 b = *reinterpret_cast<const uint4*>(qp + s * 64 + 16);
+        qn[s] = make_v8i(a, b);
+      }
+      if constexpr (FMT == 0) {
+        const uint16_t* rp = g_q_rope + qrow * kDR + lh * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qr[s] = as_bf8(*reinterpret_cast<const uint4*>(rp + s * 16));
+        qs = g_q_scale[qrow] * p.scale_log2e;
+      } else {
+        qr8 = make_v8i(*reinterpret_cast<const uint4*>(qp + 512), *reinterpret_cast<const uint4*>(qp + 528));
+        qs = (p.descale_q ? *p.descale_q : 1.f) * p.scale_log2e;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) qn[s] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    int L_row = L;
+    if (p.causal) L_row = L - (p.s_q - 1 - row / p.h_q);   // query j sees keys [0, L - (s_q-1-j))
+    if (!row_ok) L_row = 0;
+    const int L_min = p.causal ? L - (p.s_q - 1) : L;
+
+    ReqState st;
+    float mo_preset = kNegRef;
+    // pass 0 fixes the O reference at each row's first valid page; pass 1 runs only if some block reference outran it
+    // by more than kMaxUp (page_step), with the reference preset to the final one
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st.o[j][r] = 0.f;
+      FL_SLOT_END();
+    }
+    st.l[0] = st.l[1] = st.lq[0] = st.lq[1] = 0.f;
+    st.mw[0] = st.mw[1] = kNegRef;
+    st.mo = mo_preset;
+    st.redo = 0;
+
+    // page ids of a 64-page window live in ONE VGPR (lane j = page win_base + j); a lookup is a v_readlane
+    int win_base = 0;
+    int pg_vec = 0;
+    auto load_window = [&](int base) {
+      win_base = base;
+      const int t = base + lane;
+      int pg = 0;
+      if (t < n) pg = g_block_table[(long long)req * p.bt_stride + tile_b + t];
+      pg_vec = (pg < 0 || pg >= p.num_pages) ? 0 : pg;
+    };
+    load_window(0);
+    auto page_of = [&](int t) { return (long long)__builtin_amdgcn_readlane(pg_vec, t - win_base); };
+
+    // every wave finished with the LDS of the previous request; the Q loads above leave the vmcnt queue
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    auto src_nope_of = [&](int t) { return g_k_nope + page_of(t) * (kPage * kTokBytes); };
+    auto src_rope_of = [&](int t) {
+      return FMT == 0 ? reinterpret_cast<const uint8_t*>(g_k_rope) + page_of(t) * (kPage * kRopeTok)
+                      : g_k_nope + page_of(t) * (kPage * kTokBytes);
+    };
+    auto src_scale_of = [&](int t) { return FMT == 0 ? g_k_scale + page_of(t) * kPage : g_k_scale; };
+    auto ring = [&](int t) { return smem + kOffRing + (t & 3) * kSlotBytes; };
+    auto rope_slot = [&](int t) { return smem + kOffRope + (t % kRopeSlots) * kRopeBytes; };
+    auto scale_slot = [&](int t) { return reinterpret_cast<float*>(smem + kOffScale + (t % kRopeSlots) * (kPage * 4)); };
+    float* scr = reinterpret_cast<float*>(smem + kOffScratch + wave * kScratchPerWave);
+    // ---- prologue.  Issue order (the counted waits rely on it): r0 s0 n0 | r1 s1 n1 | n2, then step j issues
+    //      r(j+2) s(j+2) n(j+3).  At the top of step i everything up to {n(i), r(i), s(i)} must have landed, i.e. at most
+    //      {n(i+1), r(i+1), s(i+1)} and {n(i+2)} may still be in flight. ----
+    auto dma_rs = [&](int t) {
+      const LaneConst lc = opaque(lc0);
+      const uint8_t* sr = src_rope_of(t);
+#pragma unroll
+      for (int k = 0; k < kRopePerWave; ++k)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sr + lc.dr[k]),
+                                         (lds_ptr_t)(rope_slot(t) + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
+      if constexpr (FMT == 0)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale_of(t) + lane), (lds_ptr_t)scale_slot(t), 4, 0, 0);
+    };
+    auto dma_n = [&](int t) {
+      const LaneConst lc = opaque(lc0);
+      const uint8_t* sn = src_nope_of(t);
+#pragma unroll
+      for (int k = 0; k < kNopePerWave; ++k)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sn + dn_off<FMT>(lc, k)),
+                                         (lds_ptr_t)(ring(t) + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
+    };
+    if (n > 0) { dma_rs(0); dma_n(0); }
+    if (n > 1) { dma_rs(1); dma_n(1); }
+    if (n > 2) dma_n(2);
+
+    for (int i = 0; i < n; ++i) {
+      if (i + 3 >= win_base + 64 && i + 3 < n) load_window(i + 2);   // pages i+2 .. i+65
+      const uint8_t* sn = nullptr;
+      const uint8_t* sr = nullptr;
+      const float* ss = nullptr;
+      if (i + 3 < n) sn = src_nope_of(i + 3);
+      if (i + 2 < n) {
+        sr = src_rope_of(i + 2);
+        ss = src_scale_of(i + 2);
+      }
+      const int ahead = n - 1 - i < 2 ? n - 1 - i : 2;
+      const int tok0 = (tile_b + i) * kPage;
+      page_step<FMT>(st, lc0, qn, qr, qr8, qs, ks_const, wave, ring(i), rope_slot(i), scale_slot(i), scr, ring(i + 3),
+                     rope_slot(i + 2), scale_slot(i + 2), sn, sr, ss, tok0, L, L_row, tok0 + kPage > L_min, ahead FL_T_ARGS);
+    }
+    if (pass == 1) break;
+    {
+      // workgroup-uniform decision (the page loop has workgroup barriers)
+      int* flag = reinterpret_cast<int*>(smem + kOffFlag);
+      const int vote = __any(st.redo != 0) ? 1 : 0;
+      if (lane == 0) flag[wave] = vote;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int any_redo = flag[0] | flag[1] | flag[2] | flag[3];
+      if (!any_redo) break;
+      mo_preset = fmaxf(st.mw[0], st.mw[1]);
+    }
+    }   // pass
+
+    // ---- per-request epilogue: merge the normalisers of the two blocks and lane halves, normalise, store ----
+    FL_MFMA_DRAIN();
+    const float f0 = __builtin_amdgcn_exp2f(st.mw[0] - st.mo), f1 = __builtin_amdgcn_exp2f(st.mw[1] - st.mo);
+    float l = st.l[0] * f0 + st.l[1] * f1;
+    float lq = st.lq[0] * f0 + st.lq[1] * f1;
+    l += __shfl_xor(l, 32);
+    lq += __shfl_xor(lq, 32);
+    const float inv = lq > 0.f ? 1.f / lq : 0.f;
+    const float lse_nat = l > 0.f ? (__builtin_amdgcn_logf(l) + st.mo - kPShift) * 0.6931471805599453f : -INFINITY;
+    // split-KV partials are normalised by lq, so they are COMBINED with lq-based weights; the exact LSE travels along
+    const float lseq_nat = lq > 0.f ? (__builtin_amdgcn_logf(lq) + st.mo - kPShift) * 0.6931471805599453f : -INFINITY;
+    if (row_ok) {
+      const int slot_idx = split_base + split_idx;
+      if (lh == 0) {
+        if (is_split) {
+          p.lse_accum[((long long)slot_idx * p.rows + row) * 2 + 0] = lseq_nat;
+          p.lse_accum[((long long)slot_idx * p.rows + row) * 2 + 1] = lse_nat;
+        } else {
+          const int j = row / p.h_q, h = row - j * p.h_q;
+          p.lse[((long long)req * p.h_q + h) * p.s_q + j] = lse_nat;
+        }
+      }
+      // C row i = e + 8g + 4*lh of tile (dh, jb)  ->  d = 256dh + (jb>>2)*128 + (jb&3)*16 + (i&15) + 64*(i>>4)
+      if (is_split) {
+        float* dbase = p.o_accum + ((long long)slot_idx * p.rows + row) * kDN;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int jb = t & 7, i0 = 8 * g + 4 * lh;
+            const int d0 = (t >> 3) * 256 + (jb >> 2) * 128 + (jb & 3) * 16 + (i0 & 15) + 64 * (i0 >> 4);
+            *reinterpret_cast<float4*>(dbase + d0) = make_float4(st.o[t][g * 4 + 0] * inv, st.o[t][g * 4 + 1] * inv,
+                                                                  st.o[t][g * 4 + 2] * inv, st.o[t][g * 4 + 3] * inv);
+            if (g == 3) FL_SLOT_END();
+          }
+      } else {
+        uint16_t* dbase = p.out + qrow * kDN;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int jb = t & 7, i0 = 8 * g + 4 * lh;
+            const int d0 = (t >> 3) * 256 + (jb >> 2) * 128 + (jb & 3) * 16 + (i0 & 15) + 64 * (i0 >> 4);
+            const uint32_t lo = (uint32_t)fl_f32_to_bf16(st.o[t][g * 4 + 0] * inv) |
+                                ((uint32_t)fl_f32_to_bf16(st.o[t][g * 4 + 1] * inv) << 16);
+            const uint32_t hi = (uint32_t)fl_f32_to_bf16(st.o[t][g * 4 + 2] * inv) |
+                                ((uint32_t)fl_f32_to_bf16(st.o[t][g * 4 + 3] * inv) << 16);
+            *reinterpret_cast<uint2*>(dbase + d0) = make_uint2(lo, hi);
+            if (g == 3) FL_SLOT_END();
+          }
+      }
+    }
+#ifdef FL_MLA_TIMING
+    FL_T(5);   // epilogue
+#endif
+  }
+#ifdef FL_MLA_TIMING
+  if (g_dbg_x != nullptr && lane == 0) {
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(g_dbg_x) + ((long long)blockIdx.x * 4 + wave) * 10;
+    for (int i = 0; i < 8; ++i) d[i] = tacc[i];
+    d[8] = __builtin_readcyclecounter() - tstart;
+    d[9] = tlast - tstart;
+  }
+#endif
+}
+
+}  // namespace
+
+int fl_mla_decode_fp8_x_impl(const FlMlaDecodeArgs* a, const Params& p, hipStream_t stream) {
+  const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(64 * kNW);
+  if (a->kv_format == FL_KV_FP8_PER_TOKEN)
+    mla_decode_x_kernel<0><<<grid, block, 0, stream>>>(p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata,
+                                                        a->num_splits, (const uint8_t*)a->k_nope,
+                                                        (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope,
+                                                        (const uint16_t*)a->q_rope, a->q_scale);
+  else
+    mla_decode_x_kernel<1><<<grid, block, 0, stream>>>(p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata,
+                                                        a->num_splits, (const uint8_t*)a->k_nope,
+                                                        (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope,
+                                                        (const uint16_t*)a->q_rope, a->q_scale);
+  FL_CHECK_LAUNCH("mla_decode_x_kernel");
+  return fl_mla_launch_combine(p, a->num_splits, stream);
+}
+
+#ifdef FL_MLA_TIMING
+extern "C" int fl_mla_debug_set_buffer_x(int* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_x), &dev_ptr, sizeof(dev_ptr));
+}
+#endif

@@ -12,18 +12,25 @@ wl = bench.build_workload(dev, 1, bench.BS, bench.SEQ, H, seed=1)
 meta, ns = fm.get_mla_metadata(wl["seqlens"], H, 1)
 qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
 pages = wl["pages"]
-nblocks = meta.shape[0] * ((H + 63) // 64)
+XK = H > 64
+nblocks = meta.shape[0] * ((H + 127) // 128 if XK else (H + 63) // 64)
 dbg = torch.zeros(nblocks * 4 * 10 * 2, dtype=torch.int32, device=dev)
-lib.fl_mla_debug_set_buffer.argtypes = [ctypes.c_void_p]
-lib.fl_mla_debug_set_buffer(dbg.data_ptr())
+setter = lib.fl_mla_debug_set_buffer_x if XK else lib.fl_mla_debug_set_buffer
+setter.argtypes = [ctypes.c_void_p]
+setter(dbg.data_ptr())
 k_lora, k_scale, k_rope = wl["caches"][0]
 for _ in range(3):
     fm.flash_mla_ckv_fp8_per_token(qn, qr, k_lora.view(pages, 64, 1, 512), k_rope.view(pages, 64, 1, 64), qs,
                                    k_scale.view(pages, 64, 1, 1), wl["block_table"], wl["seqlens"], 512, meta, ns, bench.SCALE, True)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().view(np.uint64).reshape(nblocks * 4, 10).astype(np.float64)
+if XK:
+    names_x = ["wait page + barrier", "DMA issue + triples", "QK (24 MFMA)", "softmax", "PV (16 MFMA)", "epilogue", "-", "-"]
 names = ["prep(scale scratch)", "QK issue+Vt prefetch", "softmax+P publish", "waits+barrier", "DMA issue", "P fetch+O ref", "PV issue", "-"]
 tiles = bench.SEQ // 64
+if XK:
+    names = names_x
+    tiles = tiles * bench.BS / meta.shape[0]   # pages per workgroup
 tot = d[:, 8].mean()
 print(f"H={H}: mean wave lifetime {tot:.0f} ticks; per page {tot/tiles:.0f} (s_memtime ticks, 100 MHz const clock -> x{2200/100:.0f} for ~cycles)")
 for i in range(7):
