@@ -119,72 +119,6 @@ __device__ __forceinline__ void kblock_body(v16f (&acc)[MT], const uint8_t* __re
   }
 }
 
-// Compute-regime variant (128-token tile): the operands of k block kb+1 are read from LDS while the MFMAs of k block
-// kb run (register double buffer), so the matrix pipe does not wait for ds_read latency behind every barrier.
-template <int MT>
-struct Operands {
-  uint4 wa[4];
-  uint4 ab[MT][4];
-  float sc[MT];
-};
-
-template <int MT>
-__device__ __forceinline__ void kblock_pipelined(v16f (&acc)[MT], const Operands<MT>& cur, Operands<MT>& nxt,
-                                                 const uint8_t* __restrict__ rd_w, const uint8_t* __restrict__ rd_a,
-                                                 const float* __restrict__ rd_as, uint8_t* __restrict__ dma_w,
-                                                 uint8_t* __restrict__ dma_a, float* __restrict__ dma_as,
-                                                 const uint8_t* const (&src_w)[4], const uint8_t* const (&src_a)[MT],
-                                                 const float* const (&src_as)[Smem<MT>::kAsFloats / 64], const long long k_off,
-                                                 const long long as_off, const bool issue, const bool has_next,
-                                                 const bool more_in_flight, const float ws_next, const int (&rb)[4],
-                                                 const int wave, const int li) {
-  constexpr int kAsPieces = Smem<MT>::kAsFloats / 64;
-  static_assert(MT == 4, "vmcnt immediate below is for MT = 4");
-  // ---- stage kb+1 landed for every wave; stage kb+2 may stay in flight ----
-  if (more_in_flight)
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // 1 stage x (4 + 4 + 2) pieces
-  else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (issue) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_w[k] + k_off), (lds_ptr_t)(dma_w + (wave * 4 + k) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int k = 0; k < MT; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_a[k] + k_off), (lds_ptr_t)(dma_a + (wave * MT + k) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int k = 0; k < kAsPieces; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_as[k] + as_off), (lds_ptr_t)(dma_as + k * 64), 4, 0, 0);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // ---- operands of the NEXT k block: in flight under the MFMAs below ----
-  if (has_next) {
-    const uint8_t* wp = rd_w + wave * (32 * BK);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) nxt.wa[s] = *reinterpret_cast<const uint4*>(wp + rb[s]);
-#pragma unroll
-    for (int j = 0; j < MT; ++j)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) nxt.ab[j][s] = *reinterpret_cast<const uint4*>(rd_a + j * (32 * BK) + rb[s]);
-#pragma unroll
-    for (int j = 0; j < MT; ++j) nxt.sc[j] = rd_as[j * 32 + li] * ws_next;
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // ---- MFMAs of the CURRENT k block (operands already in registers) ----
-  const v8i a0 = mk8(cur.wa[0], cur.wa[1]), a1 = mk8(cur.wa[2], cur.wa[3]);
-#pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    v16f part;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[r] = 0.f;
-    part = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, mk8(cur.ab[j][0], cur.ab[j][1]), part, 0, 0, 0, kUnit, 0, kUnit);
-    part = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, mk8(cur.ab[j][2], cur.ab[j][3]), part, 0, 0, 0, kUnit, 0, kUnit);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = fmaf(part[r], cur.sc[j], acc[j][r]);
-  }
-}
-
 template <int MT>
 __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void grouped_gemm_fp8_kernel(const GemmParams p, const uint8_t* __restrict__ gA,
                                                                    const float* __restrict__ gAs,
@@ -309,45 +243,13 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void grouped_gemm_fp8_kernel(
     if (s < KB) issue_stage(s);
 
   const float* wsrow = gWs + ((long long)e * ((p.N + BN - 1) / BN) + nt) * KB;
-  if constexpr (MT == 4) {
-    // register-double-buffered pipeline: iteration kb certifies stage kb+1, prefetches its operands, computes kb
-    Operands<MT> opA, opB;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // prologue stages (<= 3) landed: simplest correct start
-    __builtin_amdgcn_s_barrier();
-    {
-      const uint8_t* wp = stage_w(0) + wave * (32 * BK);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) opA.wa[s] = *reinterpret_cast<const uint4*>(wp + rb[s]);
-#pragma unroll
-      for (int j = 0; j < MT; ++j)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) opA.ab[j][s] = *reinterpret_cast<const uint4*>(stage_a(0) + j * (32 * BK) + rb[s]);
-#pragma unroll
-      for (int j = 0; j < MT; ++j) opA.sc[j] = stage_as(0)[j * 32 + li] * wsrow[0];
-    }
-    auto step = [&](int kb, const Operands<MT>& cur, Operands<MT>& nxt) {
-      const int st1 = (kb + 1) % kStages;                   // stage whose operands are prefetched
-      const int nst = (kb + kStages - 1) % kStages;         // stage refilled (freed: its operands were read at kb-2)
-      const bool has_next = kb + 1 < KB;
-      kblock_pipelined<MT>(acc, cur, nxt, stage_w(st1), stage_a(st1), stage_as(st1), stage_w(nst), stage_a(nst),
-                           stage_as(nst), wsrc, asrc, assrc, (long long)(kb + kStages - 1) * BK,
-                           (long long)(kb + kStages - 1) * p.as_stride_k, kb + kStages - 1 < KB, has_next, kb + 2 < KB,
-                           has_next ? wsrow[kb + 1] : 0.f, rb, wave, li);
-    };
-    int kb = 0;
-    for (; kb + 1 < KB; kb += 2) {
-      step(kb, opA, opB);
-      step(kb + 1, opB, opA);
-    }
-    if (kb < KB) step(kb, opA, opB);
-  } else {
-    for (int kb = 0; kb < KB; ++kb) {
-      const int st = kb % kStages;
-      const int nst = (kb + kStages - 1) % kStages;
-      kblock_body<MT>(acc, stage_w(st), stage_a(st), stage_as(st), stage_w(nst), stage_a(nst), stage_as(nst), wsrc, asrc,
-                      assrc, (long long)(kb + kStages - 1) * BK, (long long)(kb + kStages - 1) * p.as_stride_k,
-                      kb + kStages - 1 < KB, kb + kStages - 2 < KB, wsrow[kb], rb, wave, li);
-    }
+  // (a register-double-buffered variant of the 128-token tile was measured slower: 678 vs 833 TFLOP/s at T=16384)
+  for (int kb = 0; kb < KB; ++kb) {
+    const int st = kb % kStages;
+    const int nst = (kb + kStages - 1) % kStages;
+    kblock_body<MT>(acc, stage_w(st), stage_a(st), stage_as(st), stage_w(nst), stage_a(nst), stage_as(nst), wsrc, asrc,
+                    assrc, (long long)(kb + kStages - 1) * BK, (long long)(kb + kStages - 1) * p.as_stride_k,
+                    kb + kStages - 1 < KB, kb + kStages - 2 < KB, wsrow[kb], rb, wave, li);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
