@@ -71,6 +71,8 @@ struct ReqState {
   float l[2], lq[2];     // exact / rounded-weight normalisers per block, relative to mw[b]
   float mw[2];           // integer softmax references per block
   float mo;              // reference of O (fixed once set)
+  v8i pb;                // fp8 weights of the previous page (PV pending): bytes 0..15 block 0, 16..31 block 1
+  int sb;                // ... and this lane's E8M0 block scale for them
   int redo;              // a block reference outran mo by more than kMaxUp: repeat the request with mo preset
 };
 
@@ -116,20 +118,22 @@ __device__ __forceinline__ v4i as_v4i(const v8bf b) {
   return x.i;
 }
 __device__ __forceinline__ void mfma_rope_first(v16f& acc, const uint4 a, const v8bf b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(as_v4i(a)), "v"(as_v4i(b)));
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(as_v4i(a)), "v"(as_v4i(b)) : "memory");
 }
 __device__ __forceinline__ void mfma_rope(v16f& acc, const uint4 a, const v8bf b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(as_v4i(a)), "v"(as_v4i(b)));
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(as_v4i(a)), "v"(as_v4i(b)) : "memory");
 }
 __device__ __forceinline__ void mfma_fp8_first(v16f& acc, const v8i a, const v8i b) {
   asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]"
                : "=&v"(acc)
-               : "v"(a), "v"(b), "v"(kUnitScale));
+               : "v"(a), "v"(b), "v"(kUnitScale)
+               : "memory");
 }
 __device__ __forceinline__ void mfma_fp8(v16f& acc, const v8i a, const v8i b) {
   asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
                : "+v"(acc)
-               : "v"(a), "v"(b), "v"(kUnitScale));
+               : "v"(a), "v"(b), "v"(kUnitScale)
+               : "memory");
 }
 #define FL_MFMA_DRAIN() asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory")
 
@@ -162,9 +166,11 @@ __device__ __forceinline__ void sm_scale(Soft& c, const int g, const float qs, c
       if (!(y[e] == y[e])) y[e] = -INFINITY;   // NaN can only come from garbage beyond the row's limit
     }
   }
+  c.tmax = fmaxf(fmaxf(c.tmax, fmaxf(y[0], y[1])), fmaxf(y[2], y[3]));
+  // pin: the chunk's results are "used" here, so that the optimiser cannot sink its VALU work out of the MFMA slot
+  asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(c.tmax));
 #pragma unroll
   for (int e = 0; e < 4; ++e) c.y[g * 4 + e] = y[e];
-  c.tmax = fmaxf(fmaxf(c.tmax, fmaxf(y[0], y[1])), fmaxf(y[2], y[3]));
 }
 __device__ __forceinline__ void sm_ref(Soft& c, const float* __restrict__ scr, const int b, const int lh, float& m_w,
                                        float& l_run, float& lq_run) {
@@ -175,6 +181,7 @@ __device__ __forceinline__ void sm_ref(Soft& c, const float* __restrict__ scr, c
   lq_run *= f;
   m_w = m_new;
   c.moff = kPShift - m_new;
+  asm volatile("" : "+v"(l_run), "+v"(lq_run), "+v"(m_w), "+v"(c.moff));   // pin (see sm_scale)
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     c.a4[g] = *reinterpret_cast<const float4*>(scr + 2 * kPage + 32 * b + g * 8 + lh * 4);
@@ -197,6 +204,7 @@ __device__ __forceinline__ void sm_exp(Soft& c, const int g, float& l_run, float
   lq_run = fmaf(d01[1], c.a4[g].y, lq_run);
   lq_run = fmaf(d23[0], c.a4[g].z, lq_run);
   lq_run = fmaf(d23[1], c.a4[g].w, lq_run);
+  asm volatile("" : "+v"(l_run), "+v"(lq_run), "+v"(c.pk[g]));   // pin (see sm_scale)
 }
 // chunk k (0..9) of a block's softmax: 0 = scales of group 0; 1..4 = scale + max of group k-1 (and the scales of
 // group k); 5 = reference (and the 1/k_scale loads); 6..9 = exp groups
@@ -217,12 +225,15 @@ __device__ __forceinline__ void sm_chunk(Soft& c, const int k, const float* __re
 }
 
 // QK of block b with the softmax chunks of ANOTHER block interleaved (SOFT = false: none).  12 slots (FMT 0).
-template <int FMT, bool SOFT>
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+template <int FMT, bool SOFT, class Hook = NoHook>
 __device__ __forceinline__ v16f qk_stage(const LaneConst& lc, const uint8_t* __restrict__ k_nope,
                                          const uint8_t* __restrict__ k_rope, const int b, const v8i (&qn)[8],
                                          const v8bf (&qr)[4], const v8i qr8, Soft& c, const float* __restrict__ scr,
                                          const int sb_, const int lh, const float qs, const int tok0, const int L_row,
-                                         const bool need_mask, float& m_w, float& l_run, float& lq_run) {
+                                         const bool need_mask, float& m_w, float& l_run, float& lq_run,
+                                         const Hook& hook = Hook()) {
   const uint8_t* kp = k_nope + b * (32 * kDN);
   const uint8_t* rp = k_rope + b * (32 * (FMT == 0 ? kDR * 2 : kDR));
   uint4 ra[4];
@@ -242,6 +253,7 @@ __device__ __forceinline__ v16f qk_stage(const LaneConst& lc, const uint8_t* __r
       if (s == 0) mfma_rope_first(acc, ra[s], qr[s]);
       else mfma_rope(acc, ra[s], qr[s]);
       if (SOFT && (s & 1)) { sm_chunk(c, chunk, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run); ++chunk; }
+      hook(s);
       FL_SLOT_END();
     }
   } else {
@@ -252,6 +264,7 @@ __device__ __forceinline__ v16f qk_stage(const LaneConst& lc, const uint8_t* __r
       sm_chunk(c, 2, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
       chunk = 3;
     }
+    hook(0); hook(1); hook(2); hook(3);
     FL_SLOT_END();
   }
 #pragma unroll
@@ -262,6 +275,7 @@ __device__ __forceinline__ v16f qk_stage(const LaneConst& lc, const uint8_t* __r
       sm_chunk(c, chunk, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
       ++chunk;
     }
+    hook(4 + s);
     FL_SLOT_END();
   }
   FL_MFMA_DRAIN();   // acc is read by VALU instructions next
@@ -286,118 +300,143 @@ __device__ __forceinline__ unsigned dn_off(const LaneConst& lc, const int k) {
   return lc.dn_row + (unsigned)k * 2u * kTokBytes + (lc.dn_x ^ ((unsigned)k << 5));
 }
 
-// One page of one request for one wave.  All LDS regions are distinct __restrict__ parameters of ONE inlined function
-// (see mla_decode_fp8.hip: otherwise hipcc drains the LDS-DMA queue with vmcnt(0) before every ds_read).
-template <int FMT>
+// One pipeline step of one wave.  The first (no previous page) and last (no current page) steps are separate
+// instantiations OUTSIDE the page loop; inside the loop there is exactly one variant — two variants joined inside the
+// loop, or a run-time condition around the PV MFMAs, make hipcc copy all 256 O registers at the join:
+//     QK block 0 of page i
+//     QK block 1 of page i        ||  softmax of block 0 of page i
+//     PV of page i-1 (16 MFMAs)   ||  softmax of block 1 of page i
+// so the VALU / transcendental work of a block always sits in the shadow of independent MFMAs.  All LDS regions are
+// distinct __restrict__ parameters of ONE inlined function (see mla_decode_fp8.hip: otherwise hipcc drains the LDS-DMA
+// queue with vmcnt(0) before every ds_read).
+template <int FMT, bool has_cur, bool has_prev>
 __device__ __forceinline__ void page_step(
     ReqState& st, const LaneConst& lc_in, const v8i (&qn)[8], const v8bf (&qr)[4], const v8i qr8, const float qs,
     const float ks_const, const int wave,
     // ---- page i: latent slot, rope slot, raw scales; wave-private triple scratch
     const uint8_t* __restrict__ k_nope, const uint8_t* __restrict__ k_rope, const float* __restrict__ k_scale_raw,
     float* __restrict__ scr,
-    // ---- LDS regions filled by the DMA issued in this call (never read in this call)
+    // ---- page i-1: latent slot (V^T)
+    const uint8_t* __restrict__ v_nope,
+    // ---- LDS regions filled by the DMA issued in this call (page i+2; never read in this call)
     uint8_t* __restrict__ dma_nope, uint8_t* __restrict__ dma_rope, float* __restrict__ dma_scale,
     const uint8_t* __restrict__ src_nope, const uint8_t* __restrict__ src_rope, const float* __restrict__ src_scale,
     // ---- geometry
-    const int tok0, const int L, const int L_row, const bool need_mask, const int pages_ahead FL_T_PARAMS) {
+    const int tok0, const int L, const int L_row, const bool need_mask, const bool next_in_flight FL_T_PARAMS) {
   constexpr int kRopePerWave = (FMT == 0 ? 8 : 4) / kNW;
-  // The lane constants are made opaque per step: otherwise LICM hoists every derived LDS/global address (dozens of
-  // loop-invariant registers) out of the page loop and the step no longer fits next to the 256-register O accumulator.
   const LaneConst lc = opaque(lc_in);
   const int lane = lc.lane, li = lc.li, lh = lc.lh;
 
-  // ---- page i landed for every wave (issue order per step: rope, scale, latent; see the kernel's page loop); every
-  //      wave is done with page i-1, whose slots are refilled below ----
-  if (pages_ahead >= 2) {
-    if constexpr (FMT == 0) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");   // latent i+1 | rope, scale i+1 | latent i+2
-    else asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-  } else if (pages_ahead == 1) {
-    if constexpr (FMT == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  // ---- page i landed for every wave (issue order per step: rope, scale, latent of ONE page); every wave is done with
+  //      page i-2, whose slots are refilled below ----
+#ifndef FL_X_NOWAIT   // experiment switch: timing without the page-landed wait (results are garbage)
+  if (next_in_flight) {
+    if constexpr (FMT == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");   // page i+1: 2 rope + 1 scale + 8 latent
     else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+#endif
+  FL_T(6);   // wait for page i
   __builtin_amdgcn_s_barrier();
-  FL_T(0);   // wait for page i + barrier
-  if (src_rope != nullptr) {
-#pragma unroll
-    for (int k = 0; k < kRopePerWave; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_rope + lc.dr[k]),
+  FL_T(0);   // barrier
+  // The LDS-DMA refill (page i+2: 2 rope + 1 scale + 8 latent pieces per wave, in this order — the counted waits rely
+  // on it) and the scale triples of page i are spread over the 12 MFMA slots of QK block 0: issued in one burst at the
+  // top of the step they cost 100-185 cycles per piece (measured: 820 + most of a 2700-cycle QK stage).
+  const bool do_dma = src_nope != nullptr;
+  auto dma_piece = [&](const int k) {   // k = 0 .. kRopePerWave + (FMT == 0) + kNopePerWave - 1
+    if (k < kRopePerWave) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_rope + lc.dr[k < kRopePerWave ? k : 0]),
                                        (lds_ptr_t)(dma_rope + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
-    if constexpr (FMT == 0)
+    } else if (FMT == 0 && k == kRopePerWave) {
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
-  }
-  if (src_nope != nullptr) {
+    } else {
+      const int kk = k - kRopePerWave - (FMT == 0 ? 1 : 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_nope + dn_off<FMT>(lc, kk)),
+                                       (lds_ptr_t)(dma_nope + (wave * kNopePerWave + kk) * 1024), 16, 0, 0);
+    }
+  };
+  constexpr int kPieces = kRopePerWave + (FMT == 0 ? 1 : 0) + kNopePerWave;   // 11 / 9: fits the 12 (9) slots
+  if constexpr (!has_cur) {
+    if (do_dma) {
 #pragma unroll
-    for (int k = 0; k < kNopePerWave; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_nope + dn_off<FMT>(lc, k)),
-                                       (lds_ptr_t)(dma_nope + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
-  }
-
-  {
-    // scale triples of the page (lane = token), wave-private scratch
-    float ks = FMT == 0 ? k_scale_raw[lane] : ks_const;
-    if (tok0 + lane >= L || !(ks > 0.f) || !(ks < 3.0e38f)) ks = 1.f;
-    scr[lane] = ks;
-    scr[kPage + lane] = __builtin_amdgcn_logf(ks);
-    scr[2 * kPage + lane] = __builtin_amdgcn_rcpf(ks);
-    {
-      // tail of the sequence: zero the rows past the end (P' is exactly 0 there, but 0*NaN would poison the PV MFMA)
-      if (tok0 + kPage > L) {
-        const int nvalid = L - tok0;
-        uint8_t* wr = const_cast<uint8_t*>(k_nope);
-#pragma clang loop vectorize(disable) unroll(disable)
-        for (int T = nvalid + lh; T < kPage; T += 2)
-          *reinterpret_cast<uint4*>(wr + T * kDN + li * 16) = make_uint4(0, 0, 0, 0);
-      }
+      for (int k = 0; k < kPieces; ++k) dma_piece(k);
     }
   }
-  FL_SLOT_END();
-  FL_T(1);   // DMA issue + scale triples
 
-  // ---- A. S^T blocks 0 and 1; the softmax of block 0 rides in the MFMA shadow of block 1 ----
   Soft c0, c1;
-  c0.y = qk_stage<FMT, false>(lc, k_nope, k_rope, 0, qn, qr, qr8, c1, scr, 0, lh, qs, tok0, L_row, need_mask,
-                             st.mw[0], st.l[0], st.lq[0]);
-  FL_SLOT_END();
-  c1.y = qk_stage<FMT, FL_X_OVERLAP>(lc, k_nope, k_rope, 1, qn, qr, qr8, c0, scr, 0, lh, qs, tok0, L_row, need_mask,
-                                     st.mw[0], st.l[0], st.lq[0]);
-  FL_SLOT_END();
-  FL_T(2);   // QK
-  // ---- B. the rest of the softmax ----
-  if constexpr (!FL_X_OVERLAP) {
-#pragma unroll
-    for (int k = 0; k < kSoftChunks; ++k) sm_chunk(c0, k, scr, 0, lh, qs, tok0, L_row, need_mask, st.mw[0], st.l[0], st.lq[0]);
+  if constexpr (has_cur) {
+    float ks_raw = ks_const;
+    if constexpr (FMT == 0) ks_raw = k_scale_raw[lane];   // consumed two slots later
+    // tail of the sequence: zero the rows past the end (P' is exactly 0 there, but 0*NaN would poison the PV MFMA)
+    if (tok0 + kPage > L) {
+      const int nvalid = L - tok0;
+      uint8_t* wr = const_cast<uint8_t*>(k_nope);
+#pragma clang loop vectorize(disable) unroll(disable)
+      for (int T = nvalid + lh; T < kPage; T += 2)
+        *reinterpret_cast<uint4*>(wr + T * kDN + li * 16) = make_uint4(0, 0, 0, 0);
+    }
     FL_SLOT_END();
+    FL_T(1);   // tail fill
+    auto hook = [&](const int slot) {
+      if (slot == 2) {
+        // scale triples of the page (lane = token), wave-private scratch; first read by the softmax in QK block 1
+        float ks = ks_raw;
+        if (tok0 + lane >= L || !(ks > 0.f) || !(ks < 3.0e38f)) ks = 1.f;
+        scr[lane] = ks;
+        scr[kPage + lane] = __builtin_amdgcn_logf(ks);
+        scr[2 * kPage + lane] = __builtin_amdgcn_rcpf(ks);
+      }
+      constexpr int kSlots = FMT == 0 ? 12 : 9;
+      if (do_dma && slot < kSlots && slot < kPieces) dma_piece(slot);
+    };
+    // ---- A. S^T blocks 0 and 1; the softmax of block 0 rides in the MFMA shadow of block 1 ----
+    c0.y = qk_stage<FMT, false>(lc, k_nope, k_rope, 0, qn, qr, qr8, c1, scr, 0, lh, qs, tok0, L_row, need_mask,
+                               st.mw[0], st.l[0], st.lq[0], hook);
+    FL_SLOT_END();
+    FL_T(2);   // QK block 0
+    c1.y = qk_stage<FMT, true>(lc, k_nope, k_rope, 1, qn, qr, qr8, c0, scr, 0, lh, qs, tok0, L_row, need_mask,
+                              st.mw[0], st.l[0], st.lq[0]);
+    FL_SLOT_END();
+    FL_T(3);   // QK block 1 || softmax 0
   }
-#pragma unroll
-  for (int k = 0; k < kSoftChunks; ++k) sm_chunk(c1, k, scr, 1, lh, qs, tok0, L_row, need_mask, st.mw[1], st.l[1], st.lq[1]);
-  FL_SLOT_END();
-  FL_T(3);   // softmax
 
-  // ---- C. O^T += V^T · P^T.  The reference of O is fixed when a row sees its first valid token and NEVER moves in
-  //      this pass: later blocks with a larger reference m_b enter with an E8M0 block scale 2^(m_b - mo) > 1 (exact;
-  //      fp32 O has the range).  Only a reference more than kMaxUp above mo (a logit that beats the row's first-page
-  //      maximum by > 69 nats) cannot be represented: it raises st.redo and the kernel repeats the request with mo
-  //      preset to the final reference.  So O is touched by nothing but the MFMA in the page loop. ----
-  const float mw_max = fmaxf(st.mw[0], st.mw[1]);
-  st.mo = st.mo > kNegRef ? st.mo : mw_max;
-  st.redo |= (mw_max - st.mo > kMaxUp) ? 1 : 0;
-  int sb = 127 + (int)fminf((lh ? st.mw[1] : st.mw[0]) - st.mo, kMaxUp);
-  sb = sb < 0 ? 0 : sb;
-  const v8i pb = make_v8i(make_uint4(c0.pk[0], c0.pk[1], c0.pk[2], c0.pk[3]),
-                          make_uint4(c1.pk[0], c1.pk[1], c1.pk[2], c1.pk[3]));
-  v8i va[3];
-  va[0] = vt_load(lc, k_nope, 0);
-  va[1] = vt_load(lc, k_nope, 1);
-  FL_SLOT_END();
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    if (t + 2 < 16) va[(t + 2) % 3] = vt_load(lc, k_nope, t + 2);
-    st.o[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[t % 3], pb, st.o[t], 0, 0, 0, kUnitScale, 0, sb);
+  // ---- C. O^T += V^T(i-1) · P^T(i-1), with the softmax of block 1 of page i in the MFMA shadow.  Nothing but the
+  //      MFMA touches O in the page loop (see the finalisation below for the fixed O reference). ----
+  {
+    const v8i pb = st.pb;
+    const int sb = st.sb;
+    v8i va[3];
+    if constexpr (has_prev) {
+      va[0] = vt_load(lc, v_nope, 0);
+      va[1] = vt_load(lc, v_nope, 1);
+    }
     FL_SLOT_END();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      if constexpr (has_prev) {
+        if (t + 2 < 16) va[(t + 2) % 3] = vt_load(lc, v_nope, t + 2);
+        st.o[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[t % 3], pb, st.o[t], 0, 0, 0, kUnitScale, 0, sb);
+      }
+      if (has_cur && t < kSoftChunks)
+        sm_chunk(c1, t, scr, 1, lh, qs, tok0, L_row, need_mask, st.mw[1], st.l[1], st.lq[1]);
+      FL_SLOT_END();
+    }
   }
-  FL_T(4);   // PV issue
+  if constexpr (has_cur) {
+    // The reference of O is fixed when a row sees its first valid token and NEVER moves in this pass: later blocks with
+    // a larger reference m_b enter with an E8M0 block scale 2^(m_b - mo) > 1 (exact; fp32 O has the range).  Only a
+    // reference more than kMaxUp above mo (a logit that beats the row's first-page maximum by > 69 nats) cannot be
+    // represented: it raises st.redo and the kernel repeats the request with mo preset to the final reference.
+    const float mw_max = fmaxf(st.mw[0], st.mw[1]);
+    st.mo = st.mo > kNegRef ? st.mo : mw_max;
+    st.redo |= (mw_max - st.mo > kMaxUp) ? 1 : 0;
+    const int sb = 127 + (int)fminf((lh ? st.mw[1] : st.mw[0]) - st.mo, kMaxUp);
+    st.sb = sb < 0 ? 0 : sb;
+    st.pb = make_v8i(make_uint4(c0.pk[0], c0.pk[1], c0.pk[2], c0.pk[3]),
+                     make_uint4(c1.pk[0], c1.pk[1], c1.pk[2], c1.pk[3]));
+  }
+  FL_T(4);   // PV || softmax 1
 }
 
 template <int FMT>
@@ -478,6 +517,53 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     const int split_base = g_num_splits[req];
     const bool is_split = (g_num_splits[req + 1] - split_base) > 1;
 
+    // page ids of a 64-page window live in ONE VGPR (lane j = page win_base + j); a lookup is a v_readlane
+    int win_base = 0;
+    int pg_vec = 0;
+    auto load_window = [&](int base) {
+      win_base = base;
+      const int t = base + lane;
+      int pg = 0;
+      if (t < n) pg = g_block_table[(long long)req * p.bt_stride + tile_b + t];
+      pg_vec = (pg < 0 || pg >= p.num_pages) ? 0 : pg;
+    };
+    load_window(0);
+    auto page_of = [&](int t) { return (long long)__builtin_amdgcn_readlane(pg_vec, t - win_base); };
+
+    // every wave finished with the LDS of the previous request (and its stores left the vmcnt queue)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    auto src_nope_of = [&](int t) { return g_k_nope + page_of(t) * (kPage * kTokBytes); };
+    auto src_rope_of = [&](int t) {
+      return FMT == 0 ? reinterpret_cast<const uint8_t*>(g_k_rope) + page_of(t) * (kPage * kRopeTok)
+                      : g_k_nope + page_of(t) * (kPage * kTokBytes);
+    };
+    auto src_scale_of = [&](int t) { return FMT == 0 ? g_k_scale + page_of(t) * kPage : g_k_scale; };
+    auto ring = [&](int t) { return smem + kOffRing + (t & 3) * kSlotBytes; };
+    auto rope_slot = [&](int t) { return smem + kOffRope + (t % kRopeSlots) * kRopeBytes; };
+    auto scale_slot = [&](int t) { return reinterpret_cast<float*>(smem + kOffScale + (t % kRopeSlots) * (kPage * 4)); };
+    float* scr = reinterpret_cast<float*>(smem + kOffScratch + wave * kScratchPerWave);
+    // ---- prologue: pages 0 and 1 (issue order per page: rope, scale, latent — the counted waits rely on it), issued
+    //      BEFORE the Q loads and the O initialisation so that their HBM latency overlaps; step 0 waits with vmcnt(0) ----
+    auto dma_page = [&](int t) {
+      const LaneConst lc = opaque(lc0);
+      const uint8_t* sr = src_rope_of(t);
+#pragma unroll
+      for (int k = 0; k < kRopePerWave; ++k)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sr + lc.dr[k]),
+                                         (lds_ptr_t)(rope_slot(t) + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
+      if constexpr (FMT == 0)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale_of(t) + lane), (lds_ptr_t)scale_slot(t), 4, 0, 0);
+      const uint8_t* sn = src_nope_of(t);
+#pragma unroll
+      for (int k = 0; k < kNopePerWave; ++k)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sn + dn_off<FMT>(lc, k)),
+                                         (lds_ptr_t)(ring(t) + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
+    };
+    if (n > 0) dma_page(0);
+    if (n > 1) dma_page(1);
+
     // ---- Q fragments (B operands), once per request ----
     const long long qrow = (long long)req * p.rows + row;
     v8i qn[8];
@@ -529,74 +615,42 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     st.mw[0] = st.mw[1] = kNegRef;
     st.mo = mo_preset;
     st.redo = 0;
+    st.sb = 0;
+    st.pb = v8i{0, 0, 0, 0, 0, 0, 0, 0};
 
-    // page ids of a 64-page window live in ONE VGPR (lane j = page win_base + j); a lookup is a v_readlane
-    int win_base = 0;
-    int pg_vec = 0;
-    auto load_window = [&](int base) {
-      win_base = base;
-      const int t = base + lane;
-      int pg = 0;
-      if (t < n) pg = g_block_table[(long long)req * p.bt_stride + tile_b + t];
-      pg_vec = (pg < 0 || pg >= p.num_pages) ? 0 : pg;
-    };
-    load_window(0);
-    auto page_of = [&](int t) { return (long long)__builtin_amdgcn_readlane(pg_vec, t - win_base); };
-
-    // every wave finished with the LDS of the previous request; the Q loads above leave the vmcnt queue
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    auto src_nope_of = [&](int t) { return g_k_nope + page_of(t) * (kPage * kTokBytes); };
-    auto src_rope_of = [&](int t) {
-      return FMT == 0 ? reinterpret_cast<const uint8_t*>(g_k_rope) + page_of(t) * (kPage * kRopeTok)
-                      : g_k_nope + page_of(t) * (kPage * kTokBytes);
-    };
-    auto src_scale_of = [&](int t) { return FMT == 0 ? g_k_scale + page_of(t) * kPage : g_k_scale; };
-    auto ring = [&](int t) { return smem + kOffRing + (t & 3) * kSlotBytes; };
-    auto rope_slot = [&](int t) { return smem + kOffRope + (t % kRopeSlots) * kRopeBytes; };
-    auto scale_slot = [&](int t) { return reinterpret_cast<float*>(smem + kOffScale + (t % kRopeSlots) * (kPage * 4)); };
-    float* scr = reinterpret_cast<float*>(smem + kOffScratch + wave * kScratchPerWave);
-    // ---- prologue.  Issue order (the counted waits rely on it): r0 s0 n0 | r1 s1 n1 | n2, then step j issues
-    //      r(j+2) s(j+2) n(j+3).  At the top of step i everything up to {n(i), r(i), s(i)} must have landed, i.e. at most
-    //      {n(i+1), r(i+1), s(i+1)} and {n(i+2)} may still be in flight. ----
-    auto dma_rs = [&](int t) {
-      const LaneConst lc = opaque(lc0);
-      const uint8_t* sr = src_rope_of(t);
-#pragma unroll
-      for (int k = 0; k < kRopePerWave; ++k)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sr + lc.dr[k]),
-                                         (lds_ptr_t)(rope_slot(t) + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
-      if constexpr (FMT == 0)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale_of(t) + lane), (lds_ptr_t)scale_slot(t), 4, 0, 0);
-    };
-    auto dma_n = [&](int t) {
-      const LaneConst lc = opaque(lc0);
-      const uint8_t* sn = src_nope_of(t);
-#pragma unroll
-      for (int k = 0; k < kNopePerWave; ++k)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sn + dn_off<FMT>(lc, k)),
-                                         (lds_ptr_t)(ring(t) + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
-    };
-    if (n > 0) { dma_rs(0); dma_n(0); }
-    if (n > 1) { dma_rs(1); dma_n(1); }
-    if (n > 2) dma_n(2);
-
-    for (int i = 0; i < n; ++i) {
-      if (i + 3 >= win_base + 64 && i + 3 < n) load_window(i + 2);   // pages i+2 .. i+65
-      const uint8_t* sn = nullptr;
-      const uint8_t* sr = nullptr;
-      const float* ss = nullptr;
-      if (i + 3 < n) sn = src_nope_of(i + 3);
-      if (i + 2 < n) {
-        sr = src_rope_of(i + 2);
-        ss = src_scale_of(i + 2);
-      }
-      const int ahead = n - 1 - i < 2 ? n - 1 - i : 2;
-      const int tok0 = (tile_b + i) * kPage;
-      page_step<FMT>(st, lc0, qn, qr, qr8, qs, ks_const, wave, ring(i), rope_slot(i), scale_slot(i), scr, ring(i + 3),
-                     rope_slot(i + 2), scale_slot(i + 2), sn, sr, ss, tok0, L, L_row, tok0 + kPage > L_min, ahead FL_T_ARGS);
+    if (pass == 1) {   // (pass 0 issued its prologue before the Q loads)
+      load_window(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (n > 0) dma_page(0);
+      if (n > 1) dma_page(1);
     }
+
+    // ---- n + 1 pipeline steps: step i = QK(i), softmax(i) || PV(i-1) ----
+#define FL_STEP(HC, HP)                                                                                                \
+  {                                                                                                                    \
+    if (i + 2 >= win_base + 64 && i + 2 < n) load_window(i + 2); /* pages i+2 .. i+65 */                               \
+    const uint8_t* sn = nullptr;                                                                                       \
+    const uint8_t* sr = nullptr;                                                                                       \
+    const float* ss = nullptr;                                                                                         \
+    if (i + 2 < n) {                                                                                                   \
+      sn = src_nope_of(i + 2);                                                                                         \
+      sr = src_rope_of(i + 2);                                                                                         \
+      ss = src_scale_of(i + 2);                                                                                        \
+    }                                                                                                                  \
+    const int tok0 = (tile_b + i) * kPage;                                                                             \
+    page_step<FMT, HC, HP>(st, lc0, qn, qr, qr8, qs, ks_const, wave, ring(i), rope_slot(i), scale_slot(i), scr,        \
+                           ring(i + 3), ring(i + 2), rope_slot(i + 2), scale_slot(i + 2), sn, sr, ss, tok0, L, L_row,  \
+                           tok0 + kPage > L_min, i > 0 && i + 1 < n FL_T_ARGS);                                                 \
+  }
+    FL_T(7);   // request prologue (window, DMA of pages 0/1, Q loads, O init)
+    if (n > 0) {
+      int i = 0;
+      FL_STEP(true, false);
+      for (i = 1; i < n; ++i) FL_STEP(true, true);
+      FL_STEP(false, true);
+    }
+#undef FL_STEP
     if (pass == 1) break;
     {
       // workgroup-uniform decision (the page loop has workgroup barriers)
@@ -633,34 +687,60 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
           p.lse[((long long)req * p.h_q + h) * p.s_q + j] = lse_nat;
         }
       }
-      // C row i = e + 8g + 4*lh of tile (dh, jb)  ->  d = 256dh + (jb>>2)*128 + (jb&3)*16 + (i&15) + 64*(i>>4)
-      if (is_split) {
-        float* dbase = p.o_accum + ((long long)slot_idx * p.rows + row) * kDN;
+    }
+    // O -> memory through a wave-private LDS transpose (the ring is free now).  A lane holds ONE row, 4 dims at a time:
+    // stored directly, every store instruction would touch 64 rows x 16 B (store-issue-bound, measured 26k cycles per
+    // workgroup).  Tiles 4c..4c+3 cover the contiguous dims [128c, 128c+128) (C row i = e + 8g + 4lh of tile 4c + jq is
+    // d = 128c + 16jq + (i&15) + 64(i>>4)), so chunk c is staged as [32 rows][128 f32] (+4 pad) and leaves as full
+    // 512-B (f32 partial) / 256-B (bf16 output) row segments.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave is past its last K / V^T read
+    {
+      constexpr int kStgStride = 128 + 4;   // floats per staged row
+      // (opaque lane id: keeps the store addresses from being hoisted out of the request loop and spilled)
+      int lane = lc0.lane;
+      asm volatile("" : "+v"(lane));
+      const int li = lane & 31, lh = lane >> 5;
+      float* stg = reinterpret_cast<float*>(smem + kOffRing) + wave * (32 * kStgStride);
+      const int row0 = rgrp * (32 * kNW) + wave * 32;
+      const int slot_idx = split_base + split_idx;
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int jb = t & 7, i0 = 8 * g + 4 * lh;
-            const int d0 = (t >> 3) * 256 + (jb >> 2) * 128 + (jb & 3) * 16 + (i0 & 15) + 64 * (i0 >> 4);
-            *reinterpret_cast<float4*>(dbase + d0) = make_float4(st.o[t][g * 4 + 0] * inv, st.o[t][g * 4 + 1] * inv,
-                                                                  st.o[t][g * 4 + 2] * inv, st.o[t][g * 4 + 3] * inv);
-            if (g == 3) FL_SLOT_END();
+            const int d_off = 16 * jq + 8 * (g & 1) + 4 * lh + 64 * (g >> 1);
+            *reinterpret_cast<float4*>(stg + li * kStgStride + d_off) =
+                make_float4(st.o[4 * c + jq][g * 4 + 0] * inv, st.o[4 * c + jq][g * 4 + 1] * inv,
+                            st.o[4 * c + jq][g * 4 + 2] * inv, st.o[4 * c + jq][g * 4 + 3] * inv);
           }
-      } else {
-        uint16_t* dbase = p.out + qrow * kDN;
+          FL_SLOT_END();
+        }
+        if (is_split) {
+          float* dbase = p.o_accum + ((long long)slot_idx * p.rows + row0) * kDN + 128 * c + (lane & 31) * 4;
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int jb = t & 7, i0 = 8 * g + 4 * lh;
-            const int d0 = (t >> 3) * 256 + (jb >> 2) * 128 + (jb & 3) * 16 + (i0 & 15) + 64 * (i0 >> 4);
-            const uint32_t lo = (uint32_t)fl_f32_to_bf16(st.o[t][g * 4 + 0] * inv) |
-                                ((uint32_t)fl_f32_to_bf16(st.o[t][g * 4 + 1] * inv) << 16);
-            const uint32_t hi = (uint32_t)fl_f32_to_bf16(st.o[t][g * 4 + 2] * inv) |
-                                ((uint32_t)fl_f32_to_bf16(st.o[t][g * 4 + 3] * inv) << 16);
-            *reinterpret_cast<uint2*>(dbase + d0) = make_uint2(lo, hi);
-            if (g == 3) FL_SLOT_END();
+          for (int k = 0; k < 16; ++k) {
+            const int r = (lane >> 5) + 2 * k;
+            const float4 v = *reinterpret_cast<const float4*>(stg + r * kStgStride + (lane & 31) * 4);
+            if (row0 + r < p.rows) *reinterpret_cast<float4*>(dbase + (long long)r * kDN) = v;
           }
+        } else {
+          uint16_t* dbase = p.out + ((long long)req * p.rows + row0) * kDN + 128 * c + (lane & 15) * 8;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int r = (lane >> 4) + 4 * k;
+            const float4 v0 = *reinterpret_cast<const float4*>(stg + r * kStgStride + (lane & 15) * 8);
+            const float4 v1 = *reinterpret_cast<const float4*>(stg + r * kStgStride + (lane & 15) * 8 + 4);
+            uint4 o;
+            o.x = (uint32_t)fl_f32_to_bf16(v0.x) | ((uint32_t)fl_f32_to_bf16(v0.y) << 16);
+            o.y = (uint32_t)fl_f32_to_bf16(v0.z) | ((uint32_t)fl_f32_to_bf16(v0.w) << 16);
+            o.z = (uint32_t)fl_f32_to_bf16(v1.x) | ((uint32_t)fl_f32_to_bf16(v1.y) << 16);
+            o.w = (uint32_t)fl_f32_to_bf16(v1.z) | ((uint32_t)fl_f32_to_bf16(v1.w) << 16);
+            if (row0 + r < p.rows) *reinterpret_cast<uint4*>(dbase + (long long)r * kDN) = o;
+          }
+        }
+        FL_SLOT_END();
       }
     }
 #ifdef FL_MLA_TIMING

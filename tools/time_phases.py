@@ -9,6 +9,9 @@ from fluent_mi355 import lib
 dev = torch.device("cuda:0")
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 wl = bench.build_workload(dev, 1, bench.BS, bench.SEQ, H, seed=1)
+if os.environ.get("SHARE_PAGES"):   # experiment: every request reads request 0's pages (L2 hits after the first)
+    k = int(os.environ["SHARE_PAGES"])
+    wl["block_table"] = wl["block_table"][torch.arange(bench.BS, device=dev) // k * k].contiguous()
 meta, ns = fm.get_mla_metadata(wl["seqlens"], H, 1)
 qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
 pages = wl["pages"]
@@ -25,7 +28,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().view(np.uint64).reshape(nblocks * 4, 10).astype(np.float64)
 if XK:
-    names_x = ["wait page + barrier", "DMA issue + triples", "QK (24 MFMA)", "softmax", "PV (16 MFMA)", "epilogue", "-", "-"]
+    names_x = ["barrier", "DMA issue + triples", "QK block 0", "QK block 1 || softmax 0", "PV || softmax 1", "epilogue", "vmcnt wait (page landed)", "request prologue"]
 names = ["prep(scale scratch)", "QK issue+Vt prefetch", "softmax+P publish", "waits+barrier", "DMA issue", "P fetch+O ref", "PV issue", "-"]
 tiles = bench.SEQ // 64
 if XK:
@@ -33,6 +36,6 @@ if XK:
     tiles = tiles * bench.BS / meta.shape[0]   # pages per workgroup
 tot = d[:, 8].mean()
 print(f"H={H}: mean wave lifetime {tot:.0f} ticks; per page {tot/tiles:.0f} (s_memtime ticks, 100 MHz const clock -> x{2200/100:.0f} for ~cycles)")
-for i in range(7):
+for i in range(8 if XK else 7):
     print(f"  {names[i]:24s} {d[:, i].mean()/tiles:8.1f} ticks/page  ({100*d[:, i].mean()/tot:5.1f} %)")
-print(f"  outside page loop        {(tot - d[:, :7].sum(1).mean())/tiles:8.1f} ticks/page-equivalent")
+print(f"  outside page loop        {(tot - d[:, :8].sum(1).mean())/tiles:8.1f} ticks/page-equivalent")
