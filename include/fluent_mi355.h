@@ -86,7 +86,8 @@ typedef struct FlMlaDecodeArgs {
   /* outputs */
   void* out;                /* bf16 [bs,s_q,h_q,d_nope] */
   float* lse;               /* f32 [bs,h_q,s_q] natural-log LSE */
-  float* o_accum;           /* f32 [bs+num_parts, s_q*h_q, d_nope] split-KV workspace (caller-owned) */
+  float* o_accum;           /* split-KV workspace of (bs+num_parts)*s_q*h_q*d_nope*4 bytes (caller-owned, opaque:
+                               f32 rows, or bf16 rows for the 128-row mapping; only fl_mla_decode reads it) */
   float* lse_accum;         /* f32 [bs+num_parts, s_q*h_q, 2] {weight LSE, exact LSE} workspace */
 } FlMlaDecodeArgs;
 

@@ -8,7 +8,7 @@
 #include "../../include/fluent_mi355.h"
 
 void fl_set_error(const char* fmt, ...);
-bool fl_mla_use_x();   // FLUENT_MLA_X=1 (read once): 128-row MLA decode workgroups + matching scheduler part count
+bool fl_mla_use_x();   // 128-row MLA decode workgroups for s_q*H > 64 + matching part count (FLUENT_MLA_X=0 disables)
 
 #define FL_CHECK_ARG(cond, ...)            \
   do {                                     \

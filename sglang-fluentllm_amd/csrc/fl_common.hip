@@ -16,9 +16,11 @@ void fl_set_error(const char* fmt, ...) {
 extern "C" const char* fl_last_error(void) { return g_err; }
 
 bool fl_mla_use_x() {
+  // 128-row-workgroup MLA decode mapping for s_q*H > 64 (mla_decode_fp8_x.hip): default on; FLUENT_MLA_X=0 selects the
+  // 64-row mapping (mla_decode_fp8.hip) for every shape.  Read once: the scheduler's part count depends on it.
   static const bool on = [] {
     const char* e = getenv("FLUENT_MLA_X");
-    return e != nullptr && e[0] == '1';
+    return !(e != nullptr && e[0] == '0');
   }();
   return on;
 }

@@ -729,35 +729,7 @@ __global__ __launch_bounds__(256) void mla_combine_kernel(const Params p, const 
   const int req = (int)(gw / p.rows), row = (int)(gw % p.rows);
   const int s0 = g_num_splits[req], ns = g_num_splits[req + 1] - s0;
   if (ns <= 1) return;
-  float mx = -INFINITY, mxx = -INFINITY;
-  for (int s = 0; s < ns; ++s) {
-    mx = fmaxf(mx, p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 0]);
-    mxx = fmaxf(mxx, p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 1]);
-  }
-  float den = 0.f, denx = 0.f;
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int s = 0; s < ns; ++s) {
-    const float ls = p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 0];
-    const float lx = p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 1];
-    const float wgt = (mx == -INFINITY) ? 0.f : __expf(ls - mx);
-    den += wgt;
-    denx += (mxx == -INFINITY) ? 0.f : __expf(lx - mxx);
-    const float* src = p.o_accum + ((long long)(s0 + s) * p.rows + row) * kDN + lane * 8;
-    const float4 a = *reinterpret_cast<const float4*>(src);
-    const float4 b = *reinterpret_cast<const float4*>(src + 4);
-    acc[0] += wgt * a.x; acc[1] += wgt * a.y; acc[2] += wgt * a.z; acc[3] += wgt * a.w;
-    acc[4] += wgt * b.x; acc[5] += wgt * b.y; acc[6] += wgt * b.z; acc[7] += wgt * b.w;
-  }
-  const float inv = den > 0.f ? 1.f / den : 0.f;
-  uint32_t o[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    o[i] = (uint32_t)fl_f32_to_bf16(acc[2 * i] * inv) | ((uint32_t)fl_f32_to_bf16(acc[2 * i + 1] * inv) << 16);
-  *reinterpret_cast<uint4*>(p.out + ((long long)req * p.rows + row) * kDN + lane * 8) = make_uint4(o[0], o[1], o[2], o[3]);
-  if (lane == 0) {
-    const int j = row / p.h_q, h = row - j * p.h_q;
-    p.lse[((long long)req * p.h_q + h) * p.s_q + j] = denx > 0.f ? mxx + __logf(denx) : -INFINITY;
-  }
+  combine_row(p, req, row, s0, ns, lane);
 }
 
 }  // namespace
@@ -790,8 +762,9 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   p.descale_q = a->descale_q; p.descale_k = a->descale_k;
   p.num_pages = a->num_pages; p.bt_stride = a->block_table_stride;
   p.out = (uint16_t*)a->out; p.lse = a->lse; p.o_accum = a->o_accum; p.lse_accum = a->lse_accum;
-  // rows > 64 (e.g. TP1, H=128), opt-in (FLUENT_MLA_X=1: measured slower so far): 128-row workgroups
-  // that ingest every KV byte once (mla_decode_fp8_x.hip).
+  p.partial_bf16 = 0;
+  // rows > 64 (e.g. TP1, H=128): 128-row workgroups that ingest every KV byte once (mla_decode_fp8_x.hip; FLUENT_MLA_X=0
+  // keeps the 64-row mapping).
   // rows <= 32 (e.g. the TP8 shard, H=16): one row group per workgroup (2 waves); otherwise 2 row groups (4 waves).
   // fl_mla_num_parts sizes the scheduler's part count with the same rule.
   if (fl_mla_use_x() && p.rows > 64) {

@@ -692,7 +692,7 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     // stored directly, every store instruction would touch 64 rows x 16 B (store-issue-bound, measured 26k cycles per
     // workgroup).  Tiles 4c..4c+3 cover the contiguous dims [128c, 128c+128) (C row i = e + 8g + 4lh of tile 4c + jq is
     // d = 128c + 16jq + (i&15) + 64(i>>4)), so chunk c is staged as [32 rows][128 f32] (+4 pad) and leaves as full
-    // 512-B (f32 partial) / 256-B (bf16 output) row segments.
+    // 256-B bf16 row segments (final output, or the split partial of this part).
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // every wave is past its last K / V^T read
     {
@@ -717,16 +717,11 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
           }
           FL_SLOT_END();
         }
-        if (is_split) {
-          float* dbase = p.o_accum + ((long long)slot_idx * p.rows + row0) * kDN + 128 * c + (lane & 31) * 4;
-#pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            const int r = (lane >> 5) + 2 * k;
-            const float4 v = *reinterpret_cast<const float4*>(stg + r * kStgStride + (lane & 31) * 4);
-            if (row0 + r < p.rows) *reinterpret_cast<float4*>(dbase + (long long)r * kDN) = v;
-          }
-        } else {
-          uint16_t* dbase = p.out + ((long long)req * p.rows + row0) * kDN + 128 * c + (lane & 15) * 8;
+        {
+          // split parts write the same bf16 row segments into their o_accum slot (read back by the combine kernel)
+          uint16_t* dst = is_split ? reinterpret_cast<uint16_t*>(p.o_accum) + ((long long)slot_idx * p.rows + row0) * kDN
+                                   : p.out + ((long long)req * p.rows + row0) * kDN;
+          uint16_t* dbase = dst + 128 * c + (lane & 15) * 8;
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const int r = (lane >> 4) + 4 * k;
@@ -759,8 +754,10 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
 
 }  // namespace
 
-int fl_mla_decode_fp8_x_impl(const FlMlaDecodeArgs* a, const Params& p, hipStream_t stream) {
+int fl_mla_decode_fp8_x_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipStream_t stream) {
+  Params p = p_in;
   const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(64 * kNW);
+  p.partial_bf16 = 1;   // split partials travel as bf16 rows (half the bytes of the f32 layout of mla_decode_fp8.hip)
   if (a->kv_format == FL_KV_FP8_PER_TOKEN)
     mla_decode_x_kernel<0><<<grid, block, 0, stream>>>(p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata,
                                                         a->num_splits, (const uint8_t*)a->k_nope,
@@ -772,6 +769,8 @@ int fl_mla_decode_fp8_x_impl(const FlMlaDecodeArgs* a, const Params& p, hipStrea
                                                         (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope,
                                                         (const uint16_t*)a->q_rope, a->q_scale);
   FL_CHECK_LAUNCH("mla_decode_x_kernel");
+  // (an in-kernel merge by the last-arriving part was measured: +77 us — one workgroup per request merging row by row is
+  //  latency-bound, and the bytes are the same; the combine kernel spreads them over the whole chip)
   return fl_mla_launch_combine(p, a->num_splits, stream);
 }
 

@@ -30,6 +30,7 @@ struct Params {
   float* lse;
   float* o_accum;
   float* lse_accum;
+  int partial_bf16;   // o_accum holds bf16 rows (128-row mapping) instead of f32 rows
 };
 
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -45,6 +46,51 @@ __device__ __forceinline__ v8i make_v8i(uint4 a, uint4 b) {
   v8i r;
   r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
   return r;
+}
+
+// split-KV merge of one (request, row): out[req,row,:] = sum_s w_s * o_accum[slot_s,row,:], w_s = softmax_s(weight LSE_s);
+// reported lse from the exact LSEs.  One wave per row, lane = 8 consecutive dims.
+__device__ __forceinline__ void combine_row(const Params& p, const int req, const int row, const int s0, const int ns,
+                                            const int lane) {
+  float mx = -INFINITY, mxx = -INFINITY;
+  for (int s = 0; s < ns; ++s) {
+    mx = fmaxf(mx, p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 0]);
+    mxx = fmaxf(mxx, p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 1]);
+  }
+  float den = 0.f, denx = 0.f;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < ns; ++s) {
+    const float ls = p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 0];
+    const float lx = p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 1];
+    const float wgt = (mx == -INFINITY) ? 0.f : __expf(ls - mx);
+    den += wgt;
+    denx += (mxx == -INFINITY) ? 0.f : __expf(lx - mxx);
+    float4 a, b;
+    if (p.partial_bf16) {
+      const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.o_accum) +
+                                                       ((long long)(s0 + s) * p.rows + row) * kDN + lane * 8);
+      a = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                      __uint_as_float(u.y & 0xffff0000u));
+      b = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                      __uint_as_float(u.w & 0xffff0000u));
+    } else {
+      const float* src = p.o_accum + ((long long)(s0 + s) * p.rows + row) * kDN + lane * 8;
+      a = *reinterpret_cast<const float4*>(src);
+      b = *reinterpret_cast<const float4*>(src + 4);
+    }
+    acc[0] += wgt * a.x; acc[1] += wgt * a.y; acc[2] += wgt * a.z; acc[3] += wgt * a.w;
+    acc[4] += wgt * b.x; acc[5] += wgt * b.y; acc[6] += wgt * b.z; acc[7] += wgt * b.w;
+  }
+  const float inv = den > 0.f ? 1.f / den : 0.f;
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    o[i] = (uint32_t)fl_f32_to_bf16(acc[2 * i] * inv) | ((uint32_t)fl_f32_to_bf16(acc[2 * i + 1] * inv) << 16);
+  *reinterpret_cast<uint4*>(p.out + ((long long)req * p.rows + row) * kDN + lane * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+  if (lane == 0) {
+    const int j = row / p.h_q, h = row - j * p.h_q;
+    p.lse[((long long)req * p.h_q + h) * p.s_q + j] = denx > 0.f ? mxx + __logf(denx) : -INFINITY;
+  }
 }
 
 }  // namespace fl_mla
