@@ -29,7 +29,10 @@ def test_library_exports_all_declared_symbols():
     lib.fl_version.restype = ctypes.c_int
     assert lib.fl_version() >= 100
     lib.fl_mla_num_parts.restype = ctypes.c_int
-    assert lib.fl_mla_num_parts(256, 128) == 128 and lib.fl_mla_num_parts(256, 16) == 256
+    # rows > 64 use 128-row workgroups (FLUENT_MLA_X=0: 64-row workgroups -> half as many parts)
+    assert lib.fl_mla_num_parts(256, 128) == (128 if os.environ.get("FLUENT_MLA_X") == "0" else 256)
+    assert lib.fl_mla_num_parts(256, 256) == (64 if os.environ.get("FLUENT_MLA_X") == "0" else 128)
+    assert lib.fl_mla_num_parts(256, 64) == 256 and lib.fl_mla_num_parts(256, 16) == 256
 
 
 def test_shim_modules_import_and_match_reference_names():
