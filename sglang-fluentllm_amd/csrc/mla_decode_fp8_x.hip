@@ -35,7 +35,7 @@ constexpr int kOffRope = kOffRing + kRingSlots * kSlotBytes;    // 3 x 8 KiB
 constexpr int kOffScale = kOffRope + kRopeSlots * kRopeBytes;   // 3 x 64 f32 raw k_scale
 constexpr int kScratchPerWave = 3 * kPage * 4;                  // {ks, log2 ks, 1/ks} x 64 tokens
 constexpr int kOffScratch = kOffScale + kRopeSlots * kPage * 4; // [wave 4]
-constexpr int kOffFlag = kOffScratch + kNW * kScratchPerWave;    // 4 ints: redo votes
+constexpr int kOffFlag = kOffScratch + 2 * kNW * kScratchPerWave;  // [parity 2][wave 4] scratch; then 4 ints: redo votes
 constexpr int kLdsBytes = kOffFlag + 16;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
@@ -71,8 +71,8 @@ struct ReqState {
   float l[2], lq[2];     // exact / rounded-weight normalisers per block, relative to mw[b]
   float mw[2];           // integer softmax references per block
   float mo;              // reference of O (fixed once set)
-  v8i pb;                // fp8 weights of the previous page (PV pending): bytes 0..15 block 0, 16..31 block 1
-  int sb;                // ... and this lane's E8M0 block scale for them
+  v16f s1;               // S^T block 1 of the newest page (softmax pending: it runs under the next page's QK block 0)
+  uint4 p0;              // fp8 weights of block 0 of the newest page (PV pending)
   int redo;              // a block reference outran mo by more than kMaxUp: repeat the request with mo preset
 };
 
@@ -118,22 +118,20 @@ __device__ __forceinline__ v4i as_v4i(const v8bf b) {
   return x.i;
 }
 __device__ __forceinline__ void mfma_rope_first(v16f& acc, const uint4 a, const v8bf b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(as_v4i(a)), "v"(as_v4i(b)) : "memory");
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(as_v4i(a)), "v"(as_v4i(b)));
 }
 __device__ __forceinline__ void mfma_rope(v16f& acc, const uint4 a, const v8bf b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(as_v4i(a)), "v"(as_v4i(b)) : "memory");
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(as_v4i(a)), "v"(as_v4i(b)));
 }
 __device__ __forceinline__ void mfma_fp8_first(v16f& acc, const v8i a, const v8i b) {
   asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]"
                : "=&v"(acc)
-               : "v"(a), "v"(b), "v"(kUnitScale)
-               : "memory");
+               : "v"(a), "v"(b), "v"(kUnitScale));
 }
 __device__ __forceinline__ void mfma_fp8(v16f& acc, const v8i a, const v8i b) {
   asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
                : "+v"(acc)
-               : "v"(a), "v"(b), "v"(kUnitScale)
-               : "memory");
+               : "v"(a), "v"(b), "v"(kUnitScale));
 }
 #define FL_MFMA_DRAIN() asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory")
 
@@ -141,21 +139,27 @@ __device__ __forceinline__ void mfma_fp8(v16f& acc, const v8i a, const v8i b) {
 // Lane (li, lh) holds query row li and tokens 32b + 8g + 4lh + e.  Result: 16 fp8 weights P' = 2^(y - m + 8).
 struct Soft {
   v16f y;
-  float4 a4[4], b4[2];   // a4[g]: k_scale of group g, later 1/k_scale; b4[g&1]: log2 k_scale of group g
+  float4 a4[4], b4[3];   // a4[g]: k_scale of group g, later 1/k_scale; b4[g % 3]: log2 k_scale of group g
   float tmax, moff;
   int pk[4];
 };
 constexpr int kSoftChunks = 10;
+// Every LDS read of the softmax is issued TWO chunks (MFMA slots) before its first use: the LDS round trip is ~140
+// cycles unloaded, more than one 64-cycle slot.
 __device__ __forceinline__ void sm_load_kl(Soft& c, const float* __restrict__ scr, const int g, const int b,
                                            const int lh) {
   const int tb = 32 * b + g * 8 + lh * 4;
   c.a4[g] = *reinterpret_cast<const float4*>(scr + tb);
-  c.b4[g & 1] = *reinterpret_cast<const float4*>(scr + kPage + tb);
+  c.b4[g % 3] = *reinterpret_cast<const float4*>(scr + kPage + tb);
+}
+__device__ __forceinline__ void sm_load_ik(Soft& c, const float* __restrict__ scr, const int g, const int b,
+                                           const int lh) {
+  c.a4[g] = *reinterpret_cast<const float4*>(scr + 2 * kPage + 32 * b + g * 8 + lh * 4);
 }
 __device__ __forceinline__ void sm_scale(Soft& c, const int g, const float qs, const int b, const int lh, const int tok0,
                                          const int L_row, const bool need_mask) {
   const float ksv[4] = {c.a4[g].x, c.a4[g].y, c.a4[g].z, c.a4[g].w};
-  const float lkv[4] = {c.b4[g & 1].x, c.b4[g & 1].y, c.b4[g & 1].z, c.b4[g & 1].w};
+  const float lkv[4] = {c.b4[g % 3].x, c.b4[g % 3].y, c.b4[g % 3].z, c.b4[g % 3].w};
   float y[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) y[e] = fmaf(c.y[g * 4 + e] * qs, ksv[e], lkv[e]);
@@ -172,8 +176,7 @@ __device__ __forceinline__ void sm_scale(Soft& c, const int g, const float qs, c
 #pragma unroll
   for (int e = 0; e < 4; ++e) c.y[g * 4 + e] = y[e];
 }
-__device__ __forceinline__ void sm_ref(Soft& c, const float* __restrict__ scr, const int b, const int lh, float& m_w,
-                                       float& l_run, float& lq_run) {
+__device__ __forceinline__ void sm_ref(Soft& c, float& m_w, float& l_run, float& lq_run) {
   const float tmax = fmaxf(c.tmax, __shfl_xor(c.tmax, 32));
   const float m_new = tmax > m_w ? ceilf(tmax) + kRefHeadroom : m_w;
   const float f = __builtin_amdgcn_exp2f(m_w - m_new);   // exactly 1 when the reference did not move
@@ -182,9 +185,6 @@ __device__ __forceinline__ void sm_ref(Soft& c, const float* __restrict__ scr, c
   m_w = m_new;
   c.moff = kPShift - m_new;
   asm volatile("" : "+v"(l_run), "+v"(lq_run), "+v"(m_w), "+v"(c.moff));   // pin (see sm_scale)
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-    c.a4[g] = *reinterpret_cast<const float4*>(scr + 2 * kPage + 32 * b + g * 8 + lh * 4);
 }
 __device__ __forceinline__ void sm_exp(Soft& c, const int g, float& l_run, float& lq_run) {
   const float e0 = __builtin_amdgcn_exp2f(c.y[g * 4 + 0] + c.moff);
@@ -206,25 +206,30 @@ __device__ __forceinline__ void sm_exp(Soft& c, const int g, float& l_run, float
   lq_run = fmaf(d23[1], c.a4[g].w, lq_run);
   asm volatile("" : "+v"(l_run), "+v"(lq_run), "+v"(c.pk[g]));   // pin (see sm_scale)
 }
-// chunk k (0..9) of a block's softmax: 0 = scales of group 0; 1..4 = scale + max of group k-1 (and the scales of
-// group k); 5 = reference (and the 1/k_scale loads); 6..9 = exp groups
+// chunk k (0..9) of a block's softmax:
+//   0: loads {ks, lk}(0), (1)      1: scale 0, loads (2)      2: scale 1, loads (3)      3: scale 2      4: scale 3, ik(0)
+//   5: reference, ik(1)            6: exp 0, ik(2)            7: exp 1, ik(3)            8: exp 2        9: exp 3
+template <int DUMMY = 0>
 __device__ __forceinline__ void sm_chunk(Soft& c, const int k, const float* __restrict__ scr, const int b, const int lh,
                                          const float qs, const int tok0, const int L_row, const bool need_mask,
                                          float& m_w, float& l_run, float& lq_run) {
   if (k == 0) {
     c.tmax = -INFINITY;
     sm_load_kl(c, scr, 0, b, lh);
+    sm_load_kl(c, scr, 1, b, lh);
   } else if (k <= 4) {
-    if (k < 4) sm_load_kl(c, scr, k, b, lh);
+    if (k <= 2) sm_load_kl(c, scr, k + 1, b, lh);
     sm_scale(c, k - 1, qs, b, lh, tok0, L_row, need_mask);
+    if (k == 4) sm_load_ik(c, scr, 0, b, lh);
   } else if (k == 5) {
-    sm_ref(c, scr, b, lh, m_w, l_run, lq_run);
+    sm_ref(c, m_w, l_run, lq_run);
+    sm_load_ik(c, scr, 1, b, lh);
   } else if (k < kSoftChunks) {
+    if (k <= 7) sm_load_ik(c, scr, k - 4, b, lh);
     sm_exp(c, k - 6, l_run, lq_run);
   }
 }
 
-// QK of block b with the softmax chunks of ANOTHER block interleaved (SOFT = false: none).  12 slots (FMT 0).
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 
 template <int FMT, bool SOFT, class Hook = NoHook>
@@ -239,7 +244,7 @@ __device__ __forceinline__ v16f qk_stage(const LaneConst& lc, const uint8_t* __r
   uint4 ra[4];
   ra[0] = *reinterpret_cast<const uint4*>(rp + lc.rb0);
   ra[1] = *reinterpret_cast<const uint4*>(rp + (lc.rb0 ^ (FMT == 0 ? 32 : 16)));
-  KOp ka[3];
+  KOp ka[4];   // operands are read THREE slots ahead of their MFMA (LDS round trip ~140+ cycles under load)
   ka[0] = k_load(lc, kp, 0);
   if constexpr (SOFT) sm_chunk(c, 0, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
   FL_SLOT_END();
@@ -248,16 +253,21 @@ __device__ __forceinline__ v16f qk_stage(const LaneConst& lc, const uint8_t* __r
   if constexpr (FMT == 0) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (s < 2) ra[s + 2] = *reinterpret_cast<const uint4*>(rp + (lc.rb0 ^ ((s + 2) << 5)));
-      if (s == 2) ka[1] = k_load(lc, kp, 1);
+      // hipcc drains lgkmcnt to 0 before every inline-asm MFMA (it cannot count across asm): the operand reads of
+      // later slots are therefore issued AFTER this slot's MFMA, so that a drain only ever waits for reads that are at
+      // least one full slot old
       if (s == 0) mfma_rope_first(acc, ra[s], qr[s]);
       else mfma_rope(acc, ra[s], qr[s]);
+      if (s < 2) ra[s + 2] = *reinterpret_cast<const uint4*>(rp + (lc.rb0 ^ ((s + 2) << 5)));
+      if (s == 1) ka[1] = k_load(lc, kp, 1);
+      if (s == 3) ka[2] = k_load(lc, kp, 2);
       if (SOFT && (s & 1)) { sm_chunk(c, chunk, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run); ++chunk; }
       hook(s);
       FL_SLOT_END();
     }
   } else {
     ka[1] = k_load(lc, kp, 1);
+    ka[2] = k_load(lc, kp, 2);
     mfma_fp8_first(acc, make_v8i(ra[0], ra[1]), qr8);
     if constexpr (SOFT) {
       sm_chunk(c, 1, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
@@ -269,8 +279,8 @@ __device__ __forceinline__ v16f qk_stage(const LaneConst& lc, const uint8_t* __r
   }
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
-    if (s + 2 < 8) ka[(s + 2) % 3] = k_load(lc, kp, s + 2);
-    mfma_fp8(acc, make_v8i(ka[s % 3].lo, ka[s % 3].hi), qn[s]);
+    mfma_fp8(acc, make_v8i(ka[s % 4].lo, ka[s % 4].hi), qn[s]);
+    if (s + 3 < 8) ka[(s + 3) % 4] = k_load(lc, kp, s + 3);
     if (SOFT && chunk < kSoftChunks) {
       sm_chunk(c, chunk, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
       ++chunk;
@@ -309,21 +319,29 @@ __device__ __forceinline__ unsigned dn_off(const LaneConst& lc, const int k) {
 // so the VALU / transcendental work of a block always sits in the shadow of independent MFMAs.  All LDS regions are
 // distinct __restrict__ parameters of ONE inlined function (see mla_decode_fp8.hip: otherwise hipcc drains the LDS-DMA
 // queue with vmcnt(0) before every ds_read).
-template <int FMT, bool has_cur, bool has_prev>
+template <int FMT, bool has_cur, bool has_prev, bool FAST>
 __device__ __forceinline__ void page_step(
     ReqState& st, const LaneConst& lc_in, const v8i (&qn)[8], const v8bf (&qr)[4], const v8i qr8, const float qs,
     const float ks_const, const int wave,
     // ---- page i: latent slot, rope slot, raw scales; wave-private triple scratch
     const uint8_t* __restrict__ k_nope, const uint8_t* __restrict__ k_rope, const float* __restrict__ k_scale_raw,
     float* __restrict__ scr,
-    // ---- page i-1: latent slot (V^T)
-    const uint8_t* __restrict__ v_nope,
+    // ---- page i-1: latent slot (V^T), triple scratch (written by the previous step)
+    const uint8_t* __restrict__ v_nope, const float* __restrict__ scr_prev,
     // ---- LDS regions filled by the DMA issued in this call (page i+2; never read in this call)
     uint8_t* __restrict__ dma_nope, uint8_t* __restrict__ dma_rope, float* __restrict__ dma_scale,
     const uint8_t* __restrict__ src_nope, const uint8_t* __restrict__ src_rope, const float* __restrict__ src_scale,
     // ---- geometry
-    const int tok0, const int L, const int L_row, const bool need_mask, const bool next_in_flight FL_T_PARAMS) {
+    const int tok0, const int L, const int L_row, const bool need_mask_rt, const bool need_mask_prev_rt,
+    const bool next_in_flight_rt FL_T_PARAMS) {
   constexpr int kRopePerWave = (FMT == 0 ? 8 : 4) / kNW;
+  // FAST = steady-state step: pages i-1 and i lie fully inside every row's limit (no masks, no tail fill) and page i+2
+  // exists (the refill is unconditional, page i+1 is in flight).  With these three conditions compiled out a stage is
+  // ONE basic block, and hipcc's s_waitcnt lgkmcnt(N) are counted; with the wave-uniform branches in place it falls
+  // back to lgkmcnt(0) at every block entry and the ~140-cycle LDS round trip is exposed half a dozen times per stage.
+  const bool need_mask = FAST ? false : need_mask_rt;
+  const bool need_mask_prev = FAST ? false : need_mask_prev_rt;
+  const bool next_in_flight = FAST ? true : next_in_flight_rt;
   const LaneConst lc = opaque(lc_in);
   const int lane = lc.lane, li = lc.li, lh = lc.lh;
 
@@ -343,7 +361,7 @@ __device__ __forceinline__ void page_step(
   // The LDS-DMA refill (page i+2: 2 rope + 1 scale + 8 latent pieces per wave, in this order — the counted waits rely
   // on it) and the scale triples of page i are spread over the 12 MFMA slots of QK block 0: issued in one burst at the
   // top of the step they cost 100-185 cycles per piece (measured: 820 + most of a 2700-cycle QK stage).
-  const bool do_dma = src_nope != nullptr;
+  const bool do_dma = FAST ? true : (src_nope != nullptr);
   auto dma_piece = [&](const int k) {   // k = 0 .. kRopePerWave + (FMT == 0) + kNopePerWave - 1
     if (k < kRopePerWave) {
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_rope + lc.dr[k < kRopePerWave ? k : 0]),
@@ -364,12 +382,14 @@ __device__ __forceinline__ void page_step(
     }
   }
 
+  // c1: block 1 of page i-1 (its S^T was left in st.s1 by the previous step); c0: block 0 of page i
   Soft c0, c1;
+  c1.y = st.s1;
   if constexpr (has_cur) {
     float ks_raw = ks_const;
     if constexpr (FMT == 0) ks_raw = k_scale_raw[lane];   // consumed two slots later
     // tail of the sequence: zero the rows past the end (P' is exactly 0 there, but 0*NaN would poison the PV MFMA)
-    if (tok0 + kPage > L) {
+    if (!FAST && tok0 + kPage > L) {
       const int nvalid = L - tok0;
       uint8_t* wr = const_cast<uint8_t*>(k_nope);
 #pragma clang loop vectorize(disable) unroll(disable)
@@ -390,53 +410,56 @@ __device__ __forceinline__ void page_step(
       constexpr int kSlots = FMT == 0 ? 12 : 9;
       if (do_dma && slot < kSlots && slot < kPieces) dma_piece(slot);
     };
-    // ---- A. S^T blocks 0 and 1; the softmax of block 0 rides in the MFMA shadow of block 1 ----
-    c0.y = qk_stage<FMT, false>(lc, k_nope, k_rope, 0, qn, qr, qr8, c1, scr, 0, lh, qs, tok0, L_row, need_mask,
-                               st.mw[0], st.l[0], st.lq[0], hook);
+    // ---- A. QK block 0 of page i || softmax of block 1 of page i-1; QK block 1 of page i || softmax of block 0 ----
+    c0.y = qk_stage<FMT, has_prev>(lc, k_nope, k_rope, 0, qn, qr, qr8, c1, scr_prev, 1, lh, qs, tok0 - kPage, L_row,
+                                  need_mask_prev, st.mw[1], st.l[1], st.lq[1], hook);
     FL_SLOT_END();
-    FL_T(2);   // QK block 0
-    c1.y = qk_stage<FMT, true>(lc, k_nope, k_rope, 1, qn, qr, qr8, c0, scr, 0, lh, qs, tok0, L_row, need_mask,
-                              st.mw[0], st.l[0], st.lq[0]);
+    FL_T(2);   // QK block 0 || softmax 1 of the previous page
+  } else {
+#pragma unroll
+    for (int k = 0; k < kSoftChunks; ++k)
+      sm_chunk(c1, k, scr_prev, 1, lh, qs, tok0 - kPage, L_row, need_mask_prev, st.mw[1], st.l[1], st.lq[1]);
+    FL_SLOT_END();
+  }
+
+  // ---- page i-1 is complete: fix / check the O reference and build the PV operands BEFORE the softmax of page i moves
+  //      mw[0].  The reference of O is fixed when a row sees its first valid token and NEVER moves in this pass: later
+  //      blocks with a larger reference m_b enter with an E8M0 block scale 2^(m_b - mo) > 1 (exact; fp32 O has the
+  //      range).  Only a reference more than kMaxUp above mo (a logit that beats the row's first-page maximum by > 69
+  //      nats) cannot be represented: it raises st.redo and the kernel repeats the request with mo preset. ----
+  v8i pb = v8i{0, 0, 0, 0, 0, 0, 0, 0};
+  int sb = 0;
+  if constexpr (has_prev) {
+    const float mw_max = fmaxf(st.mw[0], st.mw[1]);
+    st.mo = st.mo > kNegRef ? st.mo : mw_max;
+    st.redo |= (mw_max - st.mo > kMaxUp) ? 1 : 0;
+    sb = 127 + (int)fminf((lh ? st.mw[1] : st.mw[0]) - st.mo, kMaxUp);
+    sb = sb < 0 ? 0 : sb;
+    pb = make_v8i(st.p0, make_uint4(c1.pk[0], c1.pk[1], c1.pk[2], c1.pk[3]));
+  }
+  if constexpr (has_cur) {
+    st.s1 = qk_stage<FMT, true>(lc, k_nope, k_rope, 1, qn, qr, qr8, c0, scr, 0, lh, qs, tok0, L_row, need_mask, st.mw[0],
+                               st.l[0], st.lq[0]);
+    st.p0 = make_uint4(c0.pk[0], c0.pk[1], c0.pk[2], c0.pk[3]);
     FL_SLOT_END();
     FL_T(3);   // QK block 1 || softmax 0
   }
 
-  // ---- C. O^T += V^T(i-1) · P^T(i-1), with the softmax of block 1 of page i in the MFMA shadow.  Nothing but the
-  //      MFMA touches O in the page loop (see the finalisation below for the fixed O reference). ----
-  {
-    const v8i pb = st.pb;
-    const int sb = st.sb;
-    v8i va[3];
-    if constexpr (has_prev) {
-      va[0] = vt_load(lc, v_nope, 0);
-      va[1] = vt_load(lc, v_nope, 1);
-    }
+  // ---- C. O^T += V^T(i-1) · P^T(i-1): nothing but the MFMA touches O in the page loop ----
+  if constexpr (has_prev) {
+    v8i va[4];
+    va[0] = vt_load(lc, v_nope, 0);
+    va[1] = vt_load(lc, v_nope, 1);
+    va[2] = vt_load(lc, v_nope, 2);
     FL_SLOT_END();
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-      if constexpr (has_prev) {
-        if (t + 2 < 16) va[(t + 2) % 3] = vt_load(lc, v_nope, t + 2);
-        st.o[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[t % 3], pb, st.o[t], 0, 0, 0, kUnitScale, 0, sb);
-      }
-      if (has_cur && t < kSoftChunks)
-        sm_chunk(c1, t, scr, 1, lh, qs, tok0, L_row, need_mask, st.mw[1], st.l[1], st.lq[1]);
+      if (t + 3 < 16) va[(t + 3) % 4] = vt_load(lc, v_nope, t + 3);
+      st.o[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[t % 4], pb, st.o[t], 0, 0, 0, kUnitScale, 0, sb);
       FL_SLOT_END();
     }
   }
-  if constexpr (has_cur) {
-    // The reference of O is fixed when a row sees its first valid token and NEVER moves in this pass: later blocks with
-    // a larger reference m_b enter with an E8M0 block scale 2^(m_b - mo) > 1 (exact; fp32 O has the range).  Only a
-    // reference more than kMaxUp above mo (a logit that beats the row's first-page maximum by > 69 nats) cannot be
-    // represented: it raises st.redo and the kernel repeats the request with mo preset to the final reference.
-    const float mw_max = fmaxf(st.mw[0], st.mw[1]);
-    st.mo = st.mo > kNegRef ? st.mo : mw_max;
-    st.redo |= (mw_max - st.mo > kMaxUp) ? 1 : 0;
-    const int sb = 127 + (int)fminf((lh ? st.mw[1] : st.mw[0]) - st.mo, kMaxUp);
-    st.sb = sb < 0 ? 0 : sb;
-    st.pb = make_v8i(make_uint4(c0.pk[0], c0.pk[1], c0.pk[2], c0.pk[3]),
-                     make_uint4(c1.pk[0], c1.pk[1], c1.pk[2], c1.pk[3]));
-  }
-  FL_T(4);   // PV || softmax 1
+  FL_T(4);   // PV
 }
 
 template <int FMT>
@@ -543,7 +566,9 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     auto ring = [&](int t) { return smem + kOffRing + (t & 3) * kSlotBytes; };
     auto rope_slot = [&](int t) { return smem + kOffRope + (t % kRopeSlots) * kRopeBytes; };
     auto scale_slot = [&](int t) { return reinterpret_cast<float*>(smem + kOffScale + (t % kRopeSlots) * (kPage * 4)); };
-    float* scr = reinterpret_cast<float*>(smem + kOffScratch + wave * kScratchPerWave);
+    auto scr = [&](int t) {
+      return reinterpret_cast<float*>(smem + kOffScratch + ((t & 1) * kNW + wave) * kScratchPerWave);
+    };
     // ---- prologue: pages 0 and 1 (issue order per page: rope, scale, latent — the counted waits rely on it), issued
     //      BEFORE the Q loads and the O initialisation so that their HBM latency overlaps; step 0 waits with vmcnt(0) ----
     auto dma_page = [&](int t) {
@@ -615,8 +640,9 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     st.mw[0] = st.mw[1] = kNegRef;
     st.mo = mo_preset;
     st.redo = 0;
-    st.sb = 0;
-    st.pb = v8i{0, 0, 0, 0, 0, 0, 0, 0};
+    st.p0 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st.s1[r] = 0.f;
 
     if (pass == 1) {   // (pass 0 issued its prologue before the Q loads)
       load_window(0);
@@ -627,7 +653,7 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     }
 
     // ---- n + 1 pipeline steps: step i = QK(i), softmax(i) || PV(i-1) ----
-#define FL_STEP(HC, HP)                                                                                                \
+#define FL_STEP(HC, HP, FA)                                                                                               \
   {                                                                                                                    \
     if (i + 2 >= win_base + 64 && i + 2 < n) load_window(i + 2); /* pages i+2 .. i+65 */                               \
     const uint8_t* sn = nullptr;                                                                                       \
@@ -639,16 +665,20 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
       ss = src_scale_of(i + 2);                                                                                        \
     }                                                                                                                  \
     const int tok0 = (tile_b + i) * kPage;                                                                             \
-    page_step<FMT, HC, HP>(st, lc0, qn, qr, qr8, qs, ks_const, wave, ring(i), rope_slot(i), scale_slot(i), scr,        \
-                           ring(i + 3), ring(i + 2), rope_slot(i + 2), scale_slot(i + 2), sn, sr, ss, tok0, L, L_row,  \
-                           tok0 + kPage > L_min, i > 0 && i + 1 < n FL_T_ARGS);                                                 \
+    page_step<FMT, HC, HP, FA>(st, lc0, qn, qr, qr8, qs, ks_const, wave, ring(i), rope_slot(i), scale_slot(i), scr(i),     \
+                           ring(i + 3), scr(i + 1), ring(i + 2), rope_slot(i + 2), scale_slot(i + 2), sn, sr, ss, tok0, \
+                           L, L_row, tok0 + kPage > L_min, tok0 > L_min, i > 0 && i + 1 < n FL_T_ARGS);                \
   }
     FL_T(7);   // request prologue (window, DMA of pages 0/1, Q loads, O init)
     if (n > 0) {
       int i = 0;
-      FL_STEP(true, false);
-      for (i = 1; i < n; ++i) FL_STEP(true, true);
-      FL_STEP(false, true);
+      FL_STEP(true, false, false);
+      // steady state: pages i-1, i unmasked for every row and page i+2 present
+      int n_fast = L_min / kPage - tile_b;
+      n_fast = n_fast < n - 2 ? n_fast : n - 2;
+      for (i = 1; i < n_fast; ++i) FL_STEP(true, true, true);
+      for (; i < n; ++i) FL_STEP(true, true, false);
+      FL_STEP(false, true, false);
     }
 #undef FL_STEP
     if (pass == 1) break;
