@@ -237,7 +237,9 @@ def main():
             pass
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "mla_decode_fp8_kernel(+mla_combine_kernel)", "us_per_launch": round(per_launch_s * 1e6, 2),
+                "kernel": ("mla_decode_x_kernel" if (H * S_Q > 64 and os.environ.get("FLUENT_MLA_X") != "0")
+                           else "mla_decode_fp8_kernel") + "(+mla_combine_kernel)",
+                "us_per_launch": round(per_launch_s * 1e6, 2),
                 "algorithmic_bytes_per_launch": alg}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
