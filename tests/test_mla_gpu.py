@@ -314,3 +314,71 @@ def test_flash_mla_with_kvcache_fp8(fm, lens, H, s_q, dq, dk):
         kc[..., 512:].contiguous().view(torch.float8_e4m3fn).float().view(pages, 64, 1, 64), bt, seq, SCALE, True)
     e = (o.cpu().double() - emu).abs()
     assert float(e.mean() / emu.abs().mean().clamp_min(1e-30)) < 3e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K2-bf16: flash_mla_swap / flash_mla_fp8 .flash_mla_with_kvcache over a bf16 [pages,64,1,576] cache
+# (flashmla_backend.py:163-175, 240-254).  Oracle: exact attention in float64 over the same bf16 values; tolerance =
+# bf16 rounding of P (2^-9 per weight) and of the output.
+# ---------------------------------------------------------------------------------------------------------------------
+def make_bf16_576_case(lens, H, s_q, seed):
+    g = torch.Generator().manual_seed(seed)
+    bs = len(lens)
+    npg = [(L + 63) // 64 for L in lens]
+    pages = sum(npg) + 2
+    kc = torch.full((pages * 64, 1, 576), float("nan"), dtype=torch.bfloat16)   # NaN outside the valid tokens
+    perm = (torch.randperm(pages - 1, generator=g) + 1).tolist()
+    bt = torch.zeros(bs, max(max(npg), 1) + 1, dtype=torch.int32)
+    pi = 0
+    for b, L in enumerate(lens):
+        for j in range(npg[b]):
+            bt[b, j] = perm[pi]
+            pi += 1
+        if L > 0:
+            t = torch.arange(L)
+            loc = bt[b, (t // 64).long()].long() * 64 + t % 64
+            kc[loc] = torch.randn(L, 1, 576, generator=g).to(torch.bfloat16)
+    q = torch.randn(bs, s_q, H, 576, generator=g).to(torch.bfloat16)
+    return q, kc, bt, torch.tensor(lens, dtype=torch.int32), pages
+
+
+@pytest.mark.parametrize("lens,H,s_q", [([128], 16, 1), ([1, 63, 65, 300], 128, 1), ([70, 4, 200], 16, 4),
+                                         ([3000], 64, 1), ([33, 0, 31, 97], 8, 2), ([5000, 777], 128, 2)])
+def test_flash_mla_with_kvcache_bf16(fm, lens, H, s_q):
+    import flash_mla_swap
+    q, kc, bt, seq, pages = make_bf16_576_case(lens, H, s_q, seed=7 * H + s_q)
+    meta, ns = flash_mla_swap.get_mla_metadata(seq.to(dev()), s_q * H, 1)
+    o, lse = flash_mla_swap.flash_mla_with_kvcache(q=q.to(dev()), k_cache=kc.to(dev()).view(pages, 64, 1, 576),
+                                                   block_table=bt.to(dev()), cache_seqlens=seq.to(dev()), head_dim_v=512,
+                                                   tile_scheduler_metadata=meta, num_splits=ns, softmax_scale=SCALE,
+                                                   causal=True)
+    torch.cuda.synchronize()
+    ref, rlse = mla_ref.mla_decode_with_kvcache(q, torch.nan_to_num(kc).view(pages, 64, 1, 576), bt, seq, 512, SCALE, True)
+    o, lse = o.cpu(), lse.cpu()
+    assert torch.isfinite(o.float()).all(), "NaN/inf leaked from outside the valid tokens"
+    r = rel_mae(o, ref)
+    assert r < 6e-3, (lens, r)                                   # bf16 P (2^-9) + bf16 output rounding
+    assert float((o.double() - ref).abs().max()) < 5e-2, lens
+    m = torch.isfinite(rlse)
+    assert torch.equal(torch.isfinite(lse), m)
+    assert float((lse[m].double() - rlse[m]).abs().max()) < 2e-3, lens
+
+
+def test_bf16_decode_vs_reference_backend_golden(fm):
+    """The golden vectors are outputs of the REAL reference's TorchNativeAttnBackend over a bf16 KV buffer: the bf16
+    kernel is compared with them directly (no quantisation in between)."""
+    import flash_mla_swap
+    for name in ("cfg1", "ragged", "h128"):
+        g = load_golden(f"mla_torch_native_{name}.npz")
+        H = int(g["H"])
+        kv = bf16_from_u16(g["kv_buffer_after"]).to(dev()).contiguous()          # [slots,1,576]
+        pages = kv.shape[0] // 64
+        q = bf16_from_u16(g["q"]).to(dev()).view(-1, 1, H, 576).contiguous()
+        seq = torch.from_numpy(g["seq_lens"]).to(dev())
+        bt = torch.from_numpy(g["block_table"]).to(dev())
+        meta, ns = flash_mla_swap.get_mla_metadata(seq, H, 1)
+        o, _ = flash_mla_swap.flash_mla_with_kvcache(q, kv.view(pages, 64, 1, 576), bt, seq, 512, meta, ns,
+                                                     float(g["scaling"]), True)
+        ref = bf16_from_u16(g["o"]).view(-1, 1, H, 512)
+        r = rel_mae(o.cpu(), ref)
+        assert r < 8e-3, (name, r)   # both sides round P and the output to bf16 (different summation orders)
