@@ -133,6 +133,23 @@ int fl_quant_1x128(const void* x, int64_t M, int K, float eps, void* x_q, float*
 int fl_silu_and_mul(const void* x, int64_t M, int I, void* out_bf16, void* q_out, float* s_out, int64_t s_stride_m,
                     int64_t s_stride_k, fl_stream_t stream);
 
+/* ---- C5/C6/C7: compute half of flashinfer.comm.trtllm_{allreduce,reducescatter,allgather}_fusion
+ * (srt/layers/flashinfer_comm_fusion.py:286-401, 404-513, 516-640 <- layernorm.py:114-189, 305-359).  The exchange is one
+ * one-shot collective over RCCL (host: torch.distributed); this is everything after it in ONE kernel:
+ * v = sum_{w<num_pieces} x[w*piece_stride + (t,h)] (+ add_in) (+ residual_in)  [fp32];  residual_out = bf16(v);
+ * norm_out = bf16(v * rsqrt(mean_h v^2 + eps) * gamma)  (RMSNorm.forward_native, layernorm.py:88-112);
+ * quant_out/scale_out = 1x128 e4m3 quantisation of norm_out (scale (t,g) at t*s_stride_t + g*s_stride_g).
+ * All tensors bf16 [T, H] (gamma [H]); any output may be NULL. ---- */
+int fl_fused_add_rmsnorm(const void* x, int num_pieces, int64_t piece_stride /*elements*/, const void* add_in,
+                         const void* residual_in, const void* gamma, float eps, int64_t T, int H, void* residual_out,
+                         void* norm_out, void* quant_out, float* scale_out, int64_t s_stride_t, int64_t s_stride_g,
+                         fl_stream_t stream);
+/* C7 (layernorm.py:305-359 <- models/deepseek_v2.py:799-807): dual RMSNorm over gathered rows ag bf16 [T, D]:
+ * cols [0, q_rank) -> x_norm_out [T, q_rank] (+ optional 1x128 fp8 quant), cols [q_rank, q_rank+kv_rank) in place. */
+int fl_dual_rmsnorm(void* ag, int64_t T, int D, int q_rank, int kv_rank, const void* gamma_q, const void* gamma_kv,
+                    float eps_q, float eps_kv, void* x_norm_out, void* quant_out, float* scale_out, int64_t s_stride_t,
+                    int64_t s_stride_g, fl_stream_t stream);
+
 /* ---- C1/C2: device side of eps.fast_ep.AllToAll.dispatch / combine (srt/layers/moe/dispatcher/fast_ep.py:45-51,
  * 73-78).  The exchange is one equal-split all-to-all per direction over RCCL (host: torch.distributed); these do the
  * integer / row work around it, sync-free with static shapes.  Rows are bf16 [*, hidden], hidden % 8 == 0. ---- */

@@ -196,10 +196,40 @@ def gen_gemm():
     print("gemm", tuple(C.shape), tuple(moe_out.shape))
 
 
+def gen_rmsnorm():
+    """RMSNorm.forward_native run from the reference's own source (layernorm.py:88-112)."""
+    fwd = _ref_import.load_method_from_source("/root/reference/python/sglang/srt/layers/layernorm.py", "RMSNorm",
+                                              "forward_native",
+                                              {"torch": torch, "Optional": __import__("typing").Optional,
+                                               "Union": __import__("typing").Union, "Tuple": __import__("typing").Tuple})
+
+    class Holder:
+        pass
+
+    g = torch.Generator().manual_seed(31)
+    out = {}
+    for name, T, H in (("h7168", 5, 7168), ("q1536", 7, 1536), ("kv512", 7, 512)):
+        h = Holder()
+        h.weight = (1.0 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16)
+        h.variance_epsilon = 1e-6
+        x = (torch.randn(T, H, generator=g) * 2).to(torch.bfloat16)
+        r = torch.randn(T, H, generator=g).to(torch.bfloat16)
+        y_plain = fwd(h, x)
+        y_res, r_out = fwd(h, x, r)
+        out.update({f"{name}_w": bf(h.weight), f"{name}_x": bf(x), f"{name}_r": bf(r), f"{name}_y": bf(y_plain),
+                    f"{name}_y_res": bf(y_res), f"{name}_r_out": bf(r_out)})
+    np.savez_compressed(os.path.join(OUT, "rmsnorm_native.npz"), **out)
+    print("rmsnorm", sorted(out)[:3])
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--only-rmsnorm" in sys.argv:
+        gen_rmsnorm()
+        sys.exit(0)
     gen_mla_torch_native()
     gen_kv_quant()
     gen_alloc()
     gen_gemm()
+    gen_rmsnorm()
     print("golden written to", OUT)

@@ -729,7 +729,10 @@ __global__ __launch_bounds__(256) void mla_combine_kernel(const Params p, const 
   const int req = (int)(gw / p.rows), row = (int)(gw % p.rows);
   const int s0 = g_num_splits[req], ns = g_num_splits[req + 1] - s0;
   if (ns <= 1) return;
-  combine_row(p, req, row, s0, ns, lane);
+  if (ns == 2) combine_row<2>(p, req, row, s0, ns, lane);   // the uniform full batch: two parts per request
+  else if (ns == 3) combine_row<3>(p, req, row, s0, ns, lane);
+  else if (ns == 4) combine_row<4>(p, req, row, s0, ns, lane);
+  else combine_row<0>(p, req, row, s0, ns, lane);
 }
 
 }  // namespace

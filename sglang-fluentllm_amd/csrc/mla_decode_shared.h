@@ -50,15 +50,20 @@ __device__ __forceinline__ v8i make_v8i(uint4 a, uint4 b) {
 
 // split-KV merge of one (request, row): out[req,row,:] = sum_s w_s * o_accum[slot_s,row,:], w_s = softmax_s(weight LSE_s);
 // reported lse from the exact LSEs.  One wave per row, lane = 8 consecutive dims.
-__device__ __forceinline__ void combine_row(const Params& p, const int req, const int row, const int s0, const int ns,
+// NS > 0: compile-time split count (all loads of a row are independent and issued together); NS = 0: run-time count.
+template <int NS>
+__device__ __forceinline__ void combine_row(const Params& p, const int req, const int row, const int s0, const int ns_rt,
                                             const int lane) {
+  const int ns = NS > 0 ? NS : ns_rt;
   float mx = -INFINITY, mxx = -INFINITY;
+#pragma unroll
   for (int s = 0; s < ns; ++s) {
     mx = fmaxf(mx, p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 0]);
     mxx = fmaxf(mxx, p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 1]);
   }
   float den = 0.f, denx = 0.f;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
   for (int s = 0; s < ns; ++s) {
     const float ls = p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 0];
     const float lx = p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 1];

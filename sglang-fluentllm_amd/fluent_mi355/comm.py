@@ -1,0 +1,277 @@
+"""Host-side mirror of `flashinfer.comm` on the decode hot path (reference fork: 3rdparty/flashinfer feature/longcat_main;
+call sites python/sglang/srt/layers/flashinfer_comm_fusion.py:50-58, 86-93, 115-135, 271-283, 372-397, 485-509, 613-638).
+
+MI355X mapping.  The reference's kernels are TRT-LLM "one-shot + Lamport flag" kernels over NVLink-mapped IPC buffers.
+xGMI is a point-to-point mesh (7 links per GPU): the natural one-shot exchange is ONE RCCL collective in which every rank
+receives its peers' pieces directly (all_gather / all_to_all_single with the deterministic uneven token split of
+`get_num_tokens_per_rank`, flashinfer_comm_fusion.py:237-244), followed by ONE fused HIP kernel that reduces the received
+pieces and applies add_in + residual + RMSNorm (+ 1x128 FP8 block quantisation) — `fl_fused_add_rmsnorm` /
+`fl_dual_rmsnorm` (csrc/norm_fused.hip).  No IPC workspace is needed: the `workspace` objects only carry the process
+group.  Semantics that the (absent) third-party module leaves implicit are taken from the call sites and stated below.
+
+`norm_ops` exists so that the multi-process HOST logic can be exercised on CPU tensors with the gloo backend (tests inject a
+torch implementation); the product default is the HIP one and there is no automatic fallback."""
+from __future__ import annotations
+
+import ctypes
+import enum
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class AllReduceFusionPattern(enum.IntEnum):
+    kAllReduce = 0
+    kARResidualRMSNorm = 1
+    kARResidualRMSNormFP8Quant = 2
+    kARResidualRMSNormFP4Quant = 3
+    kARResidualRMSNormOutFP8Quant = 4
+    kARResidualRMSNormOutFP4Quant = 5
+    kARResidualRMSNormFP8BlockWiseQuant = 6
+    kARResidualRMSNormPartialOut = 7
+    kARResidualRMSNormPartialOutFP8BlockWiseQuant = 8
+
+
+class ReduceScatterFusionPattern(enum.IntEnum):
+    kReduceScatter = 0
+    kRSResidualRMSNorm = 1
+    kRSResidualRMSNormFP8BlockWiseQuant = 2
+    kRSAddResidualRMSNorm = 3
+    kRSAddResidualRMSNormFP8BlockWiseQuant = 4
+
+
+class AllGatherFusionPattern(enum.IntEnum):
+    kAllGather = 0
+    kAllGatherfusedRMS = 1
+    kAllGatherfusedRMSFP8BlockWiseQuant = 2
+
+
+def get_num_tokens_per_rank(world_size: int, total: int) -> list:
+    """flashinfer_comm_fusion.py:237-244."""
+    return [total // world_size + (1 if r < total % world_size else 0) for r in range(world_size)]
+
+
+class HipNormOps:
+    """Device implementation: every method is one C-ABI call on the current stream."""
+
+    def __init__(self):
+        from ._lib import check, lib, stream_ptr
+
+        self._check, self._lib, self._stream = check, lib, stream_ptr
+        vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+        lib.fl_fused_add_rmsnorm.argtypes = [vp, i32, i64, vp, vp, vp, f32, i64, i32, vp, vp, vp, vp, i64, i64, vp]
+        lib.fl_fused_add_rmsnorm.restype = i32
+        lib.fl_dual_rmsnorm.argtypes = [vp, i64, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp, i64, i64, vp]
+        lib.fl_dual_rmsnorm.restype = i32
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else t.data_ptr()
+
+    def add_rmsnorm(self, pieces, add_in, residual_in, gamma, eps, residual_out, norm_out, quant_out, scale_out):
+        """pieces [W, T, H] bf16 contiguous."""
+        W, T, H = pieces.shape
+        for t in (pieces, add_in, residual_in, gamma, residual_out, norm_out):
+            assert t is None or (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()), "bf16 contiguous CUDA tensors"
+        sst, ssg = (scale_out.stride(0), scale_out.stride(1)) if scale_out is not None else (0, 0)
+        self._check(self._lib.fl_fused_add_rmsnorm(pieces.data_ptr(), W, T * H, self._p(add_in), self._p(residual_in),
+                                                   gamma.data_ptr(), float(eps), T, H, self._p(residual_out),
+                                                   self._p(norm_out), self._p(quant_out), self._p(scale_out), sst, ssg,
+                                                   self._stream(pieces.device)), "fl_fused_add_rmsnorm")
+
+    def dual_rmsnorm(self, ag, q_rank, kv_rank, gamma_q, gamma_kv, eps_q, eps_kv, x_norm_out, quant_out, scale_out):
+        T, D = ag.shape
+        assert ag.is_cuda and ag.dtype == torch.bfloat16 and ag.is_contiguous()
+        sst, ssg = (scale_out.stride(0), scale_out.stride(1)) if scale_out is not None else (0, 0)
+        self._check(self._lib.fl_dual_rmsnorm(ag.data_ptr(), T, D, q_rank, kv_rank, gamma_q.data_ptr(), gamma_kv.data_ptr(),
+                                              float(eps_q), float(eps_kv), self._p(x_norm_out), self._p(quant_out),
+                                              self._p(scale_out), sst, ssg, self._stream(ag.device)), "fl_dual_rmsnorm")
+
+
+_norm_ops = None
+
+
+def set_norm_ops(ops):
+    """Tests only: inject an implementation of the two fused kernels (CPU tensors + gloo)."""
+    global _norm_ops
+    _norm_ops = ops
+
+
+def _ops():
+    global _norm_ops
+    if _norm_ops is None:
+        _norm_ops = HipNormOps()
+    return _norm_ops
+
+
+class _Workspace:
+    """What `workspace_ptrs` resolves to: the process group of the exchange (nothing is IPC-mapped on this design)."""
+
+    def __init__(self, rank, world_size, group):
+        self.rank, self.world_size, self.group = rank, world_size, group
+
+
+_registry = {}
+
+
+def _register(rank, world_size, group, device=None):
+    ws = _Workspace(rank, world_size, group)
+    tensor = torch.zeros(1, dtype=torch.int64, device=device if device is not None else "cpu")
+    _registry[id(tensor)] = ws
+    tensor._fluent_ws = ws
+    return [ws], tensor
+
+
+def _resolve(workspace_ptrs) -> _Workspace:
+    ws = getattr(workspace_ptrs, "_fluent_ws", None)
+    if ws is None:
+        ws = _registry.get(id(workspace_ptrs))
+    if ws is None:
+        raise RuntimeError("workspace_ptrs was not created by trtllm_create_ipc_workspace_for_all_reduce_fusion")
+    return ws
+
+
+def _device_of_group(group):
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() and (
+        group is None or dist.get_backend(group) == "nccl") else None
+
+
+def trtllm_create_ipc_workspace_for_all_reduce_fusion(rank, world_size, max_token_num, hidden_dim, group=None,
+                                                      use_fp32_lamport=False):
+    """flashinfer_comm_fusion.py:86-93 -> (ipc_handles, workspace_tensor)."""
+    return _register(rank, world_size, group, _device_of_group(group) if dist.is_initialized() else None)
+
+
+def trtllm_destroy_ipc_workspace_for_all_reduce_fusion(ipc_handles, group=None):
+    """flashinfer_comm_fusion.py:115-117."""
+    return None
+
+
+def destroy_ipc_workspace_for_allgather(ipc_handles, group=None):
+    """flashinfer_comm_fusion.py:133-135."""
+    return None
+
+
+def _world(ws):
+    return ws.world_size if (dist.is_initialized() and ws.world_size > 1) else 1
+
+
+def _gather_pieces(x, ws):
+    """[T, H] on every rank -> [W, T, H]: the one-shot all-reduce exchange (every rank receives every peer's tensor)."""
+    W = _world(ws)
+    if W == 1:
+        return x.unsqueeze(0)
+    buf = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(buf, x.contiguous(), group=ws.group)
+    return buf.view((W,) + tuple(x.shape))
+
+
+def trtllm_allreduce_fusion(allreduce_in, world_size, world_rank, token_num, hidden_dim, workspace_ptrs, launch_with_pdl=True,
+                            use_oneshot=None, trigger_completion_at_end=False, fp32_acc=False, pattern_code=None,
+                            allreduce_out=None, residual_in=None, residual_out=None, norm_out=None, quant_out=None,
+                            scale_out=None, rms_gamma=None, rms_eps=1e-6, scale_factor=None, layout_code=None,
+                            residual_reduce_scattered=False, max_sm_to_use=None, partial_norm_out=None):
+    """C5 (flashinfer_comm_fusion.py:372-397).  sum over ranks of `allreduce_in` [T, H]; + residual; RMSNorm; optional 1x128
+    FP8 quantisation of the norm.  `residual_reduce_scattered`: residual_in / residual_out hold only this rank's token slice
+    (`get_num_tokens_per_rank`) — every rank then adds its residual slice into its own piece before the exchange (the sum
+    contains each residual row exactly once) and keeps its slice of the new residual.  `partial_norm_out`: this rank's token
+    slice of the norm (layernorm.py:114-153 has_partial_norm_out)."""
+    ws = _resolve(workspace_ptrs)
+    W = _world(ws)
+    T, H = allreduce_in.shape
+    counts = get_num_tokens_per_rank(W, T)
+    lo = sum(counts[:world_rank]) if W > 1 else 0
+    hi = lo + (counts[world_rank] if W > 1 else T)
+    x = allreduce_in
+    res_full, res_out_full = residual_in, residual_out
+    if residual_reduce_scattered and W > 1:
+        x = allreduce_in.clone()
+        if residual_in is not None:
+            x[lo:hi] += residual_in          # enters the sum exactly once
+        res_full = None
+        res_out_full = torch.empty_like(allreduce_in) if residual_out is not None else None
+    pieces = _gather_pieces(x, ws)
+    want_norm = pattern_code is None or int(pattern_code) != int(AllReduceFusionPattern.kAllReduce)
+    if want_norm:
+        n_out = norm_out if norm_out is not None else (torch.empty_like(allreduce_in) if partial_norm_out is not None else None)
+        _ops().add_rmsnorm(pieces.contiguous(), None, res_full, rms_gamma, rms_eps, res_out_full, n_out, quant_out, scale_out)
+        if residual_reduce_scattered and W > 1 and residual_out is not None:
+            residual_out.copy_(res_out_full[lo:hi])
+        if partial_norm_out is not None:
+            partial_norm_out.copy_(n_out[lo:hi])
+    if allreduce_out is not None:
+        allreduce_out.copy_(pieces.float().sum(0).to(allreduce_out.dtype))
+
+
+def trtllm_reducescatter_fusion(reducescatter_in, world_size, world_rank, token_num, hidden_dim, workspace_ptrs,
+                                launch_with_pdl=True, trigger_completion_at_end=False, num_token_current_rank=None,
+                                fp32_acc=False, pattern_code=None, use_oneshot=None, reducescatter_out=None, add_in=None,
+                                residual_in=None, residual_out=None, norm_out=None, quant_out=None, scale_out=None,
+                                rms_gamma=None, rms_eps=1e-6, scale_factor=None, layout_code=None):
+    """C6 (flashinfer_comm_fusion.py:485-509).  This rank's token slice of the sum over ranks of `reducescatter_in` [T, H]
+    (+ add_in) + residual; RMSNorm; optional FP8 quantisation.  All per-rank tensors are [num_token_current_rank, H]."""
+    ws = _resolve(workspace_ptrs)
+    W = _world(ws)
+    T, H = reducescatter_in.shape
+    counts = get_num_tokens_per_rank(W, T)
+    mine = counts[world_rank] if W > 1 else T
+    if W == 1:
+        pieces = reducescatter_in.unsqueeze(0)
+    else:
+        # one-shot reduce-scatter: every rank receives its token slice from every peer (uneven splits), reduces locally
+        recv = torch.empty((W * mine, H), dtype=reducescatter_in.dtype, device=reducescatter_in.device)
+        dist.all_to_all_single(recv, reducescatter_in.contiguous(), output_split_sizes=[mine] * W,
+                               input_split_sizes=counts, group=ws.group)
+        pieces = recv.view(W, mine, H)
+    if pattern_code is not None and int(pattern_code) == int(ReduceScatterFusionPattern.kReduceScatter):
+        reducescatter_out.copy_(pieces.float().sum(0).to(reducescatter_out.dtype))
+        return
+    _ops().add_rmsnorm(pieces.contiguous(), add_in, residual_in, rms_gamma, rms_eps, residual_out, norm_out, quant_out, scale_out)
+    if reducescatter_out is not None:
+        reducescatter_out.copy_(pieces.float().sum(0).to(reducescatter_out.dtype))
+
+
+def trtllm_allgather_fusion(allgather_in, world_size, world_rank, hidden_dim, workspace_ptrs, launch_with_pdl=True,
+                            trigger_completion_at_end=False, num_token_current_rank=None, allgather_out=None,
+                            num_token_all_group=None, pattern_code=None, use_oneshot=True, fp32_acc=False, x_norm_out=None,
+                            y_norm_out=None, quant_out=None, scale_out=None, x_rms_gamma=None, y_rms_gamma=None,
+                            x_rms_eps=1e-6, y_rms_eps=1e-6, q_lora_rank=None, kv_lora_rank=None, qk_rope_head_dim=None):
+    """C7 (flashinfer_comm_fusion.py:613-638).  Gathers the token rows of every rank (uneven counts =
+    `get_num_tokens_per_rank(world, num_token_all_group)`) into allgather_out [total, D], then RMSNorm of the q_a columns
+    into x_norm_out (+ optional FP8 quantisation) and of the kv_a columns IN PLACE (y_norm_out aliases allgather_out,
+    flashinfer_comm_fusion.py:578-579)."""
+    ws = _resolve(workspace_ptrs)
+    W = _world(ws)
+    t_cur, D = allgather_in.shape
+    if W == 1:
+        allgather_out[:t_cur].copy_(allgather_in)
+    else:
+        counts = get_num_tokens_per_rank(W, num_token_all_group)
+        assert counts[world_rank] == t_cur, "token split does not follow get_num_tokens_per_rank"
+        send = allgather_in.contiguous().repeat(W, 1)            # the same rows to every peer
+        dist.all_to_all_single(allgather_out, send, output_split_sizes=counts, input_split_sizes=[t_cur] * W, group=ws.group)
+    if pattern_code is not None and int(pattern_code) == int(AllGatherFusionPattern.kAllGather):
+        return
+    _ops().dual_rmsnorm(allgather_out, q_lora_rank, kv_lora_rank, x_rms_gamma, y_rms_gamma, x_rms_eps, y_rms_eps, x_norm_out,
+                        quant_out, scale_out)
+
+
+# ---- flashinfer.comm.all_gather (vocab gather, flashinfer_comm_fusion.py:50-58, 271-283) ----
+def create_ipc_workspace_for_allgather(rank, world_size, max_token_num, hidden_size, use_fp32=False, group=None):
+    return _register(rank, world_size, group, _device_of_group(group) if dist.is_initialized() else None)
+
+
+def simple_all_gather(allgather_in, world_size, world_rank, token_num, hidden_size, workspace_ptrs, launch_with_pdl=True,
+                      trigger_completion_at_end=False, max_num_tokens=None, allgather_out=None, max_sm_to_use=None):
+    """[T, V_local] on every rank -> allgather_out [T, world * V_local] (rank r's columns at [r*V_local, (r+1)*V_local))."""
+    ws = _resolve(workspace_ptrs)
+    W = _world(ws)
+    if W == 1:
+        allgather_out.copy_(allgather_in)
+        return allgather_out
+    T = allgather_in.shape[0]
+    buf = torch.empty((W * T, hidden_size), dtype=allgather_in.dtype, device=allgather_in.device)
+    dist.all_gather_into_tensor(buf, allgather_in.contiguous(), group=ws.group)
+    allgather_out.view(T, W, hidden_size).copy_(buf.view(W, T, hidden_size).permute(1, 0, 2))
+    return allgather_out

@@ -1,0 +1,114 @@
+"""MI355X: the fused kernels behind flashinfer.comm.trtllm_{allreduce,reducescatter,allgather}_fusion (csrc/norm_fused.hip)
+through the drop-in API at world size 1 (the exchange is the identity; the N>1 host logic runs in test_comm_gloo_cpu.py).
+bf16 outputs must match the reference's RMSNorm.forward_native golden BIT FOR BIT up to the last-ulp differences of the
+reduction order (fp32 sum of squares): tolerance = 1 bf16 ulp on < 0.5 % of the elements; the FP8 bytes are compared against
+the oracle's quantisation of the kernel's own bf16 norm (bit-exact)."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "sglang-fluentllm_amd"))
+from helpers import bf16_from_u16, load_golden  # noqa: E402
+from oracle import gemm_ref, norm_ref  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def ulp_close(a, b, frac=5e-3):
+    """bf16 tensors equal except for <= 1 ulp on at most `frac` of the elements."""
+    ai, bi = a.cpu().view(torch.int16).int(), b.cpu().view(torch.int16).int()
+    d = (ai - bi).abs()
+    return int(d.max()) <= 1 and float((d > 0).float().mean()) <= frac
+
+
+@pytest.fixture(scope="module")
+def comm():
+    import flashinfer.comm as c
+    return c
+
+
+def test_allreduce_fusion_matches_reference_rmsnorm_golden(comm):
+    g = load_golden("rmsnorm_native.npz")
+    _, ws = comm.trtllm_create_ipc_workspace_for_all_reduce_fusion(0, 1, 64, 7168)
+    for name in ("h7168", "q1536", "kv512"):
+        w, x, r = (bf16_from_u16(g[f"{name}_{k}"]).to(dev()) for k in ("w", "x", "r"))
+        T, H = x.shape
+        norm_out, res_out = torch.empty_like(x), torch.empty_like(x)
+        quant_out = torch.empty(T, H, dtype=torch.float8_e4m3fn, device=dev())
+        # the executor's column-major scale view (fp8_kernel.py create_per_token_group_quant_fp8_output_scale)
+        Tp = (T + 3) // 4 * 4
+        scale_out = torch.empty(H // 128, Tp, dtype=torch.float32, device=dev()).permute(-1, -2)[:T]
+        comm.trtllm_allreduce_fusion(allreduce_in=x, world_size=1, world_rank=0, token_num=T, hidden_dim=H, workspace_ptrs=ws,
+                                     pattern_code=comm.AllReduceFusionPattern.kARResidualRMSNormFP8BlockWiseQuant,
+                                     residual_in=r, residual_out=res_out, norm_out=norm_out, quant_out=quant_out,
+                                     scale_out=scale_out, rms_gamma=w, rms_eps=1e-6)
+        torch.cuda.synchronize()
+        assert torch.equal(res_out.cpu(), bf16_from_u16(g[f"{name}_r_out"])), name          # x + residual: exact
+        assert ulp_close(norm_out, bf16_from_u16(g[f"{name}_y_res"])), name
+        q_ref, s_ref = gemm_ref.per_token_group_quant_fp8(norm_out.cpu().contiguous(), 128)
+        assert torch.equal(quant_out.cpu().view(torch.uint8), q_ref.view(torch.uint8)), name
+        assert torch.equal(scale_out.cpu().contiguous(), s_ref), name
+
+
+@pytest.mark.parametrize("T,H,W", [(1, 7168, 1), (7, 7168, 8), (64, 7168, 8), (5, 2048, 2), (3, 8192, 4)])
+def test_fused_add_rmsnorm_pieces(T, H, W):
+    """The C-ABI kernel itself with W received pieces + add_in + residual (what C5/C6 run after the exchange)."""
+    from fluent_mi355.comm import HipNormOps
+    g = torch.Generator().manual_seed(T * 131 + W)
+    pieces = torch.randn(W, T, H, generator=g).to(torch.bfloat16)
+    add, res = (torch.randn(T, H, generator=g).to(torch.bfloat16) for _ in range(2))
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16)
+    y_ref, r_ref = norm_ref.fused_add_rmsnorm(pieces, add, res, gamma, 1e-6)
+    norm_out = torch.empty(T, H, dtype=torch.bfloat16, device=dev())
+    res_out = torch.empty_like(norm_out)
+    HipNormOps().add_rmsnorm(pieces.to(dev()), add.to(dev()), res.to(dev()), gamma.to(dev()), 1e-6, res_out, norm_out, None, None)
+    torch.cuda.synchronize()
+    assert ulp_close(res_out, r_ref, frac=2e-2)      # fp32 sum of W+2 terms: order-dependent last bit
+    assert ulp_close(norm_out, y_ref, frac=2e-2)
+
+
+def test_reducescatter_and_allgather_fusion_world1(comm):
+    g = torch.Generator().manual_seed(5)
+    _, ws = comm.trtllm_create_ipc_workspace_for_all_reduce_fusion(0, 1, 64, 7168)
+    T, H = 9, 7168
+    x, add, res = (torch.randn(T, H, generator=g).to(torch.bfloat16) for _ in range(3))
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16)
+    y_ref, r_ref = norm_ref.fused_add_rmsnorm(x.unsqueeze(0), add, res, gamma, 1e-6)
+    norm_out = torch.empty(T, H, dtype=torch.bfloat16, device=dev())
+    res_out = torch.empty_like(norm_out)
+    comm.trtllm_reducescatter_fusion(reducescatter_in=x.to(dev()), world_size=1, world_rank=0, token_num=T, hidden_dim=H,
+                                     workspace_ptrs=ws, num_token_current_rank=T,
+                                     pattern_code=comm.ReduceScatterFusionPattern.kRSAddResidualRMSNorm, add_in=add.to(dev()),
+                                     residual_in=res.to(dev()), residual_out=res_out, norm_out=norm_out,
+                                     rms_gamma=gamma.to(dev()), rms_eps=1e-6)
+    assert ulp_close(norm_out, y_ref, frac=2e-2) and ulp_close(res_out, r_ref, frac=2e-2)
+    # C7: DeepSeek-V3 q_lora 1536 + kv_lora 512 + rope 64
+    q_rank, kv_rank, rope = 1536, 512, 64
+    D = q_rank + kv_rank + rope
+    full = torch.randn(T, D, generator=g).to(torch.bfloat16)
+    gq = (1 + 0.1 * torch.randn(q_rank, generator=g)).to(torch.bfloat16)
+    gkv = (1 + 0.1 * torch.randn(kv_rank, generator=g)).to(torch.bfloat16)
+    x_ref, ag_ref = norm_ref.dual_rmsnorm(full, q_rank, kv_rank, gq, gkv, 1e-6, 1e-6)
+    ag = torch.empty(T, D, dtype=torch.bfloat16, device=dev())
+    quant_out = torch.empty(T, q_rank, dtype=torch.float8_e4m3fn, device=dev())
+    scale_out = torch.empty(q_rank // 128, (T + 3) // 4 * 4, dtype=torch.float32, device=dev()).permute(-1, -2)[:T]
+    xn = torch.empty(T, q_rank, dtype=torch.bfloat16, device=dev())
+    comm.trtllm_allgather_fusion(allgather_in=full.to(dev()), world_size=1, world_rank=0, hidden_dim=D, workspace_ptrs=ws,
+                                 num_token_current_rank=T, allgather_out=ag, num_token_all_group=T,
+                                 pattern_code=comm.AllGatherFusionPattern.kAllGatherfusedRMSFP8BlockWiseQuant, x_norm_out=xn,
+                                 y_norm_out=ag[..., q_rank:q_rank + kv_rank], quant_out=quant_out, scale_out=scale_out,
+                                 x_rms_gamma=gq.to(dev()), y_rms_gamma=gkv.to(dev()), x_rms_eps=1e-6, y_rms_eps=1e-6,
+                                 q_lora_rank=q_rank, kv_lora_rank=kv_rank, qk_rope_head_dim=rope)
+    torch.cuda.synchronize()
+    assert ulp_close(xn, x_ref, frac=2e-2) and ulp_close(ag, ag_ref, frac=2e-2)
+    assert torch.equal(ag.cpu()[:, q_rank + kv_rank:], full[:, q_rank + kv_rank:])           # rope columns untouched
+    q_ref, s_ref = gemm_ref.per_token_group_quant_fp8(xn.cpu().contiguous(), 128)
+    assert torch.equal(quant_out.cpu().view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(scale_out.cpu().contiguous(), s_ref)

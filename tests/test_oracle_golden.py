@@ -113,3 +113,17 @@ def test_grouped_gemm_variants_agree():
     Am[2, :9], Asm[2, :9] = Aq[5:], As[5:]
     o3 = gemm_ref.grouped_gemm_masked(Am, Asm, W, Ws, torch.tensor(counts))
     assert torch.equal(o3[0, :5], o1[:5]) and torch.equal(o3[2, :9], o1[5:])
+
+
+def test_rmsnorm_oracle_matches_reference_golden():
+    """oracle.norm_ref.rmsnorm_native == RMSNorm.forward_native of the real reference (layernorm.py:88-112), bit for bit."""
+    from oracle import norm_ref
+    g = load_golden("rmsnorm_native.npz")
+    for name in ("h7168", "q1536", "kv512"):
+        w, x, r = (bf16_from_u16(g[f"{name}_{k}"]) for k in ("w", "x", "r"))
+        assert torch.equal(norm_ref.rmsnorm_native(x, w, 1e-6), bf16_from_u16(g[f"{name}_y"]))
+        y, ro = norm_ref.rmsnorm_native(x, w, 1e-6, r)
+        assert torch.equal(y, bf16_from_u16(g[f"{name}_y_res"])) and torch.equal(ro, bf16_from_u16(g[f"{name}_r_out"]))
+        # the fused statement with one piece and a residual is the same arithmetic
+        y2, r2 = norm_ref.fused_add_rmsnorm(x.unsqueeze(0), None, r, w, 1e-6)
+        assert torch.equal(y2, y) and torch.equal(r2, ro)
