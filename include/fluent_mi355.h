@@ -139,7 +139,9 @@ int fl_silu_and_mul(const void* x, int64_t M, int I, void* out_bf16, void* q_out
  * v = sum_{w<num_pieces} x[w*piece_stride + (t,h)] (+ add_in) (+ residual_in)  [fp32];  residual_out = bf16(v);
  * norm_out = bf16(v * rsqrt(mean_h v^2 + eps) * gamma)  (RMSNorm.forward_native, layernorm.py:88-112);
  * quant_out/scale_out = 1x128 e4m3 quantisation of norm_out (scale (t,g) at t*s_stride_t + g*s_stride_g).
- * All tensors bf16 [T, H] (gamma [H]); any output may be NULL. ---- */
+ * All tensors bf16 [T, H] (gamma [H]); any output may be NULL; with norm_out == quant_out == NULL it is the plain
+ * one-shot reduction (gamma may be NULL): eps.communication.TPDPConvertor.reduce_scatter (C3,
+ * srt/distributed/decoder_comm_manager.py:42-85, layers/dp_attention.py:62-74). ---- */
 int fl_fused_add_rmsnorm(const void* x, int num_pieces, int64_t piece_stride /*elements*/, const void* add_in,
                          const void* residual_in, const void* gamma, float eps, int64_t T, int H, void* residual_out,
                          void* norm_out, void* quant_out, float* scale_out, int64_t s_stride_t, int64_t s_stride_g,

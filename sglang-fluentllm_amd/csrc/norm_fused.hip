@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const uint16_t* __rest
       }
     }
   }
+  if (norm_out == nullptr && quant_out == nullptr) return;   // sum-only use (one-shot reduce-scatter, C3)
   ssq = wave_sum(ssq);
   const float rinv = rsqrtf(ssq / (float)H + eps);
 #pragma unroll
@@ -198,7 +199,8 @@ extern "C" int fl_fused_add_rmsnorm(const void* x, int num_pieces, int64_t piece
                                     const void* residual_in, const void* gamma, float eps, int64_t T, int H,
                                     void* residual_out, void* norm_out, void* quant_out, float* scale_out,
                                     int64_t s_stride_t, int64_t s_stride_g, fl_stream_t stream) {
-  FL_CHECK_ARG(x && gamma && num_pieces >= 1 && T >= 0, "fl_fused_add_rmsnorm: bad arguments");
+  FL_CHECK_ARG(x && num_pieces >= 1 && T >= 0, "fl_fused_add_rmsnorm: bad arguments");
+  FL_CHECK_ARG(gamma != nullptr || (norm_out == nullptr && quant_out == nullptr), "fl_fused_add_rmsnorm: norm needs gamma");
   FL_CHECK_ARG(H > 0 && H % 8 == 0 && H <= kMaxChunks * 512, "fl_fused_add_rmsnorm: H=%d (need H %% 8 == 0, H <= 8192)", H);
   FL_CHECK_ARG(quant_out == nullptr || (scale_out != nullptr && H % 128 == 0), "fl_fused_add_rmsnorm: quant needs scales, H %% 128 == 0");
   if (T == 0) return FL_OK;

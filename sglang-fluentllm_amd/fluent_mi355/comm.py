@@ -76,7 +76,7 @@ class HipNormOps:
             assert t is None or (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()), "bf16 contiguous CUDA tensors"
         sst, ssg = (scale_out.stride(0), scale_out.stride(1)) if scale_out is not None else (0, 0)
         self._check(self._lib.fl_fused_add_rmsnorm(pieces.data_ptr(), W, T * H, self._p(add_in), self._p(residual_in),
-                                                   gamma.data_ptr(), float(eps), T, H, self._p(residual_out),
+                                                   self._p(gamma), float(eps), T, H, self._p(residual_out),
                                                    self._p(norm_out), self._p(quant_out), self._p(scale_out), sst, ssg,
                                                    self._stream(pieces.device)), "fl_fused_add_rmsnorm")
 
@@ -275,3 +275,72 @@ def simple_all_gather(allgather_in, world_size, world_rank, token_num, hidden_si
     dist.all_gather_into_tensor(buf, allgather_in.contiguous(), group=ws.group)
     allgather_out.view(T, W, hidden_size).copy_(buf.view(W, T, hidden_size).permute(1, 0, 2))
     return allgather_out
+
+
+# ---- eps.communication.TPDPConvertor (C3): uneven reduce-scatter / all-gather inside the attention-TP group
+#      (layers/dp_attention.py:62-74; used through distributed/decoder_comm_manager.py:42-85 `RSAG`) ----
+class _RSContext:
+    def __init__(self, inp, out, offset):
+        self._inp, self._out, self.output_row_offset = inp, out, offset
+
+    def input(self):
+        return self._inp
+
+    def output(self):
+        return self._out
+
+
+class TPDPConvertor:
+    """Token rows are split over the group as `get_token_dist` does in the reference's in-tree twin of this module
+    (device_communicators/custom_triton_rsag/triton_rsag.py:48-57): rank r owns counts[r] = T//W + (r < T%W) rows at offset
+    sum(counts[:r]).  reduce_scatter: every rank receives its row slice from every peer in ONE uneven all_to_all_single
+    (direct over the xGMI mesh) and sums the W pieces in one kernel; all_gather: ONE uneven all_to_all_single."""
+
+    class Params:
+        def __init__(self, global_rank, max_num_tokens, tp_size, hidden_size, communicator=None):
+            self.global_rank, self.max_num_tokens, self.tp_size = global_rank, max_num_tokens, tp_size
+            self.hidden_size, self.communicator = hidden_size, communicator
+
+    def __init__(self, params, group=None, device=None, dtype=torch.bfloat16):
+        self.p, self.group, self.dtype = params, group, dtype
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = device if device is not None else (_device_of_group(group) if dist.is_initialized() else None) or (
+            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+
+    def get_token_dist(self, total):
+        return get_num_tokens_per_rank(self.world, total)
+
+    def get_reduce_scatter_context(self, tp_num_tokens, num_blocks=None):
+        counts = self.get_token_dist(tp_num_tokens)
+        inp = torch.empty(tp_num_tokens, self.p.hidden_size, dtype=self.dtype, device=self.device)
+        out = torch.empty(counts[self.rank], self.p.hidden_size, dtype=self.dtype, device=self.device)
+        ctx = _RSContext(inp, out, sum(counts[:self.rank]))
+        ctx.counts = counts
+        return ctx
+
+    def reduce_scatter(self, ctx, stream=None):
+        W, mine, H = self.world, ctx.counts[self.rank], self.p.hidden_size
+        if W == 1:
+            ctx.output().copy_(ctx.input())
+            return
+        recv = torch.empty(W * mine, H, dtype=self.dtype, device=self.device)
+        dist.all_to_all_single(recv, ctx.input(), output_split_sizes=[mine] * W, input_split_sizes=ctx.counts, group=self.group)
+        _ops().add_rmsnorm(recv.view(W, mine, H), None, None, None, 0.0, ctx.output(), None, None, None)
+
+    def get_all_gather_context(self, tp_num_tokens, hidden_size=None, num_blocks=None):
+        H = hidden_size if hidden_size is not None else self.p.hidden_size
+        counts = self.get_token_dist(tp_num_tokens)
+        inp = torch.empty(counts[self.rank], H, dtype=self.dtype, device=self.device)
+        out = torch.empty(tp_num_tokens, H, dtype=self.dtype, device=self.device)
+        ctx = _RSContext(inp, out, sum(counts[:self.rank]))
+        ctx.counts = counts
+        return ctx
+
+    def all_gather(self, ctx, stream=None):
+        W, mine = self.world, ctx.counts[self.rank]
+        if W == 1:
+            ctx.output().copy_(ctx.input())
+            return
+        dist.all_to_all_single(ctx.output(), ctx.input().repeat(W, 1), output_split_sizes=ctx.counts,
+                               input_split_sizes=[mine] * W, group=self.group)

@@ -10,6 +10,9 @@ from oracle import gemm_ref, norm_ref  # noqa: E402
 
 class TorchNormOps:
     def add_rmsnorm(self, pieces, add_in, residual_in, gamma, eps, residual_out, norm_out, quant_out, scale_out):
+        if gamma is None:   # sum-only (one-shot reduce-scatter)
+            residual_out.copy_(pieces.float().sum(0).to(pieces.dtype))
+            return
         y, res = norm_ref.fused_add_rmsnorm(pieces, add_in, residual_in, gamma, eps)
         if residual_out is not None:
             residual_out.copy_(res)

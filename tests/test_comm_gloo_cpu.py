@@ -104,6 +104,19 @@ def _worker(rank, world, port, T):
                                      qk_rope_head_dim=rope)
         assert torch.equal(xn, x_ref) and torch.equal(ag, ag_ref)
 
+        # ---- C3: eps.communication.TPDPConvertor, uneven reduce-scatter / all-gather (decoder_comm_manager.py:42-85) ----
+        from eps.communication import TPDPConvertor
+        conv = TPDPConvertor(TPDPConvertor.Params(rank, 64, world, H, None), device=torch.device("cpu"))
+        rs = conv.get_reduce_scatter_context(T, 45)
+        rs.input().view(dtype=torch.bfloat16).copy_(xs[rank])
+        conv.reduce_scatter(rs, None)
+        assert rs.output_row_offset == lo and torch.equal(rs.output(), pieces[:, lo:hi].float().sum(0).to(torch.bfloat16))
+        ag_ctx = conv.get_all_gather_context(T, H, 28)
+        if hi > lo:
+            ag_ctx.input().copy_(res[lo:hi])
+        conv.all_gather(ag_ctx, None)
+        assert torch.equal(ag_ctx.output(), res)
+
         # ---- vocab all-gather ----
         _, wsv = comm.all_gather.create_ipc_workspace_for_allgather(rank, world, 16, 8 * world, False, group=None)
         loc = torch.full((3, 8), float(rank + 1), dtype=torch.bfloat16)

@@ -112,3 +112,27 @@ def test_reducescatter_and_allgather_fusion_world1(comm):
     assert torch.equal(ag.cpu()[:, q_rank + kv_rank:], full[:, q_rank + kv_rank:])           # rope columns untouched
     q_ref, s_ref = gemm_ref.per_token_group_quant_fp8(xn.cpu().contiguous(), 128)
     assert torch.equal(quant_out.cpu().view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(scale_out.cpu().contiguous(), s_ref)
+
+
+def test_tpdp_convertor_world1_and_sum_kernel():
+    """C3: eps.communication.TPDPConvertor at world 1 (identity exchange) + the sum-only mode of the fused kernel that the
+    N>1 reduce-scatter runs after its exchange."""
+    from eps.communication import TPDPConvertor
+    from fluent_mi355.comm import HipNormOps
+    H, T = 7168, 13
+    conv = TPDPConvertor(TPDPConvertor.Params(0, 64, 1, H, None))
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(T, H, generator=g).to(torch.bfloat16).to(dev())
+    rs = conv.get_reduce_scatter_context(T, 45)
+    rs.input().view(dtype=torch.bfloat16).copy_(x)
+    conv.reduce_scatter(rs, torch.cuda.current_stream().cuda_stream)
+    assert rs.output_row_offset == 0 and torch.equal(rs.output(), x)
+    ag = conv.get_all_gather_context(T, H, 28)
+    ag.input().copy_(x)
+    conv.all_gather(ag, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(ag.output(), x)
+    pieces = torch.randn(8, T, H, generator=g).to(torch.bfloat16)
+    out = torch.empty(T, H, dtype=torch.bfloat16, device=dev())
+    HipNormOps().add_rmsnorm(pieces.to(dev()), None, None, None, 0.0, out, None, None, None)
+    torch.cuda.synchronize()
+    assert ulp_close(out, pieces.float().sum(0).to(torch.bfloat16), frac=2e-2)
