@@ -19,6 +19,7 @@
 //
 // Algorithmic bytes / flops per MoE layer: SURVEY.md §8(d) (weights 44.04 MB per expert hit, 88.08 MFLOP per row).
 #include "fl_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -280,6 +281,8 @@ int g_num_cus_limit = 0;   // deep_gemm.set_num_sms (tbo/tbo_executor.py:129-134
 
 }  // namespace
 
+int fl_grouped_gemm_fp8_big(const FlGemmArgs* a, hipStream_t stream);   // grouped_gemm_fp8_big.hip
+
 extern "C" int fl_gemm_set_num_cus(int n) { g_num_cus_limit = n; return FL_OK; }
 extern "C" int fl_gemm_get_num_cus(void) { return g_num_cus_limit; }
 
@@ -304,6 +307,9 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
   if (a->mode == kDense) avg = a->M;
   int mt = avg <= 32 ? 1 : (avg <= 64 ? 2 : 4);
   if (a->mode == kContiguous) mt = 4;   // groups are 128-row aligned by contract (deep_ep_executor.py:282,290)
+  // compute regime: 256 x 128 tile (FLUENT_GEMM_BIG=0 keeps the 128 x 128 tile)
+  static const bool big_ok = [] { const char* e = getenv("FLUENT_GEMM_BIG"); return !(e && e[0] == '0'); }();
+  if (big_ok && mt == 4 && avg >= 128 && a->N >= 256) return fl_grouped_gemm_fp8_big(a, (hipStream_t)stream);
   const int bm = 32 * mt;
   long long m_tiles;
   if (a->mode == kOffset) m_tiles = (a->M + bm - 1) / bm + a->num_groups;

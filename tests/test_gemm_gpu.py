@@ -101,7 +101,9 @@ def make_group_case(counts, N, K, seed):
 
 
 @pytest.mark.parametrize("counts,N,K", [([4, 0, 7, 1], 256, 512), ([0, 0, 33, 0, 64, 1, 200], 512, 256),
-                                        ([3] * 32, 4096, 7168), ([150, 70], 7168, 2048), ([0, 0, 0], 128, 128)])
+                                        ([3] * 32, 4096, 7168), ([150, 70], 7168, 2048), ([0, 0, 0], 128, 128),
+                                        # >= 128 rows per expert: the 256 x 128 tile (grouped_gemm_fp8_big.hip)
+                                        ([300, 0, 129, 511], 768, 512), ([512, 512], 4096, 7168), ([129, 640, 1], 260, 256)])
 def test_grouped_offset_vs_oracle(counts, N, K):
     import deep_gemm
 
@@ -239,3 +241,28 @@ def test_ep_all_to_all_single_rank_hip_row_ops():
     a2a.combine(out_tokens=out, weights=w.to(DEV), expert_y=y, num_global_tokens=t)
     ref = sum(w[:, k:k + 1] * (x.float() * (idx[:, k:k + 1].float() + 1)).to(torch.bfloat16).float() for k in range(K)).to(torch.bfloat16)
     assert torch.allclose(out.cpu().float(), ref.float(), atol=2e-2, rtol=2e-2)
+
+
+def test_masked_big_tile_vs_oracle():
+    """Masked mode with >= 128 expected rows per group: the 256 x 128 tile; padding rows NaN-poisoned and left untouched."""
+    import deep_gemm
+
+    G, Mp, N, K = 3, 384, 512, 512
+    masked = torch.tensor([384, 0, 130], dtype=torch.int32)
+    g = torch.Generator().manual_seed(14)
+    xm = (torch.randn(G, Mp, K, generator=g) / 3).to(torch.bfloat16)
+    aq, asc = gemm_ref.per_token_group_quant_fp8(xm, 128)
+    W = fp8_weights(g, G, N, K)
+    Ws = torch.rand(G, N // 128, K // 128, generator=g) * 1e-2
+    aq_dev = aq.clone().view(torch.uint8)
+    for gi in range(G):
+        aq_dev[gi, int(masked[gi]):] = 0x7F
+    om = torch.full((G, Mp, N), 3.0, dtype=torch.bfloat16, device=DEV)
+    deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_masked((aq_dev.to(DEV).view(torch.float8_e4m3fn), asc.to(DEV)), (W.to(DEV), Ws.to(DEV)),
+                                                    om, masked.to(DEV), 256, True)
+    refm = gemm_ref.grouped_gemm_masked(aq, asc, W, Ws, masked)
+    for gi in range(G):
+        mm = int(masked[gi])
+        if mm:
+            assert rel_mae(om[gi, :mm].cpu(), refm[gi, :mm]) < 1e-3
+        assert bool((om[gi, mm:] == 3.0).all())
