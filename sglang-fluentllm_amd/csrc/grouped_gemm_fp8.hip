@@ -23,6 +23,14 @@
 
 namespace {
 
+// Ring depth of the 128-token tile.  Measured at T=16384 (512 rows per expert), w13 / w2 TFLOP/s: 4 stages + 1 workgroup
+// per CU 838 / 492; 3 stages + 1 workgroup 820 / 481; 2 stages + 2 workgroups per CU 1233 / 846 — two INDEPENDENT
+// workgroups per CU drift apart, so one feeds the matrix pipe while the other sits in its barrier / LDS-DMA issue / LDS
+// reads.  (A 256 x 128 tile with 8 waves in ONE workgroup has fewer bytes per flop but runs in lockstep behind its
+// per-k-block barrier: 1171 / 755, software-pipelined with fenced slots 950 / 660.)
+#ifndef FL_MT4_STAGES
+#define FL_MT4_STAGES 2
+#endif
 constexpr int BN = 128;            // weight rows per workgroup (= one 128-row scale block)
 constexpr int BK = 128;            // k block (bytes per row per stage)
 constexpr int kWBytes = BN * BK;   // 16 KiB
@@ -49,9 +57,9 @@ __device__ __forceinline__ v8i mk8(uint4 a, uint4 b) {
 
 template <int MT>
 struct Smem {
-  // ring depth: small token tiles (decode regime, short K) run 2 workgroups per CU with 3 stages each so that one
-  // workgroup's prologue/epilogue overlaps the other's steady state; the 128-token tile owns the CU with 4 stages
-  static constexpr int kStages = MT == 4 ? 4 : 3;
+  // ring depth: every tile shape runs 2 workgroups per CU (3 stages for the small token tiles, 2 for the 128-token tile)
+  // so that one workgroup's barrier / DMA issue / prologue / epilogue overlaps the other's MFMAs
+  static constexpr int kStages = MT == 4 ? FL_MT4_STAGES : 3;
   static constexpr int kABytes = MT * 32 * BK;
   static constexpr int kAsFloats = MT * 32 < 64 ? 64 : MT * 32;
   static constexpr int kAsPieces = kAsFloats / 64;
@@ -77,7 +85,9 @@ __device__ __forceinline__ void kblock_body(v16f (&acc)[MT], const uint8_t* __re
   if (more_in_flight) {   // leave the (kStages - 2) later stages in flight
     if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // 1 stage x (4 + 1 + 1) pieces
     else if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");    // 1 x (4 + 2 + 1)
-    else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");                          // 2 x (4 + 4 + 2)
+    else if constexpr (FL_MT4_STAGES == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // 2 x (4 + 4 + 2)
+    else if constexpr (FL_MT4_STAGES == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -121,14 +131,14 @@ __device__ __forceinline__ void kblock_body(v16f (&acc)[MT], const uint8_t* __re
 }
 
 template <int MT>
-__global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void grouped_gemm_fp8_kernel(const GemmParams p, const uint8_t* __restrict__ gA,
+__global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void grouped_gemm_fp8_kernel(const GemmParams p, const uint8_t* __restrict__ gA,
                                                                    const float* __restrict__ gAs,
                                                                    const uint8_t* __restrict__ gW,
                                                                    const float* __restrict__ gWs,
                                                                    const int32_t* __restrict__ gmeta) {
   constexpr int BM = 32 * MT;
   constexpr int kStages = Smem<MT>::kStages;
-  static_assert(Smem<MT>::kPiecesPerWave * (kStages - 2) == (MT == 1 ? 6 : MT == 2 ? 7 : 20), "vmcnt immediates");
+  static_assert(Smem<MT>::kPiecesPerWave * (kStages - 2) == (MT == 1 ? 6 : MT == 2 ? 7 : 10 * (FL_MT4_STAGES - 2)), "vmcnt immediates");
   __shared__ __attribute__((aligned(16))) uint8_t smem[Smem<MT>::kTotal];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -281,8 +291,6 @@ int g_num_cus_limit = 0;   // deep_gemm.set_num_sms (tbo/tbo_executor.py:129-134
 
 }  // namespace
 
-int fl_grouped_gemm_fp8_big(const FlGemmArgs* a, hipStream_t stream);   // grouped_gemm_fp8_big.hip
-
 extern "C" int fl_gemm_set_num_cus(int n) { g_num_cus_limit = n; return FL_OK; }
 extern "C" int fl_gemm_get_num_cus(void) { return g_num_cus_limit; }
 
@@ -307,9 +315,6 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
   if (a->mode == kDense) avg = a->M;
   int mt = avg <= 32 ? 1 : (avg <= 64 ? 2 : 4);
   if (a->mode == kContiguous) mt = 4;   // groups are 128-row aligned by contract (deep_ep_executor.py:282,290)
-  // compute regime: 256 x 128 tile (FLUENT_GEMM_BIG=0 keeps the 128 x 128 tile)
-  static const bool big_ok = [] { const char* e = getenv("FLUENT_GEMM_BIG"); return !(e && e[0] == '0'); }();
-  if (big_ok && mt == 4 && avg >= 128 && a->N >= 256) return fl_grouped_gemm_fp8_big(a, (hipStream_t)stream);
   const int bm = 32 * mt;
   long long m_tiles;
   if (a->mode == kOffset) m_tiles = (a->M + bm - 1) / bm + a->num_groups;

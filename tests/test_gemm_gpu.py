@@ -102,7 +102,7 @@ def make_group_case(counts, N, K, seed):
 
 @pytest.mark.parametrize("counts,N,K", [([4, 0, 7, 1], 256, 512), ([0, 0, 33, 0, 64, 1, 200], 512, 256),
                                         ([3] * 32, 4096, 7168), ([150, 70], 7168, 2048), ([0, 0, 0], 128, 128),
-                                        # >= 128 rows per expert: the 256 x 128 tile (grouped_gemm_fp8_big.hip)
+                                        # >= 128 rows per expert: several 128-token tiles per expert
                                         ([300, 0, 129, 511], 768, 512), ([512, 512], 4096, 7168), ([129, 640, 1], 260, 256)])
 def test_grouped_offset_vs_oracle(counts, N, K):
     import deep_gemm
@@ -244,7 +244,7 @@ def test_ep_all_to_all_single_rank_hip_row_ops():
 
 
 def test_masked_big_tile_vs_oracle():
-    """Masked mode with >= 128 expected rows per group: the 256 x 128 tile; padding rows NaN-poisoned and left untouched."""
+    """Masked mode with >= 128 expected rows per group (128-token tiles); padding rows NaN-poisoned and left untouched."""
     import deep_gemm
 
     G, Mp, N, K = 3, 384, 512, 512
