@@ -206,9 +206,30 @@ META_W = 8
 FIXED_OVERHEAD_TILES = 2
 
 
+def _parts_needed(ntiles, capacity, limit):
+    """Parts the greedy walk needs with this capacity (stops counting beyond `limit`)."""
+    req, tile, parts, bs = 0, 0, 0, len(ntiles)
+    while req < bs and parts <= limit:
+        remain = capacity
+        parts += 1
+        while req < bs:
+            left = ntiles[req] - tile
+            if remain >= left + FIXED_OVERHEAD_TILES:
+                remain -= left + FIXED_OVERHEAD_TILES
+                req, tile = req + 1, 0
+            else:
+                take = remain - FIXED_OVERHEAD_TILES
+                if take > 0:
+                    tile += take
+                break
+    return parts
+
+
 def get_mla_metadata(cache_seqlens, num_parts: int, page_size: int = PAGE_SIZE):
-    """Greedy equal-payload partition of the row-major (request, 64-token tile) list into
-    `num_parts` contiguous parts.  Returns (meta int32 [num_parts, 8], num_splits int32 [bs+1]).
+    """Greedy partition of the row-major (request, 64-token tile) list into `num_parts` contiguous
+    parts of capacity P = the smallest value in [ceil(total/num_parts), +63] for which the greedy walk
+    places everything (fallback: ceil(total/num_parts) + FIXED_OVERHEAD).  A piece of a request costs
+    its tiles + FIXED_OVERHEAD.  Returns (meta int32 [num_parts, 8], num_splits int32 [bs+1]).
     meta row = [begin_req, begin_tile, end_req, end_tile, begin_split_idx, 0, 0, 0]: the part
     covers tiles (begin_req, begin_tile) .. (end_req, end_tile) exclusive; begin_req == bs means
     "no work".  num_splits is cumulative: request b owns accumulator slots
@@ -217,7 +238,12 @@ def get_mla_metadata(cache_seqlens, num_parts: int, page_size: int = PAGE_SIZE):
     bs = len(seqlens)
     ntiles = [((L + page_size - 1) // page_size) if L > 0 else 0 for L in seqlens]
     total = sum(n + FIXED_OVERHEAD_TILES for n in ntiles)
-    payload = max((total + num_parts - 1) // num_parts + FIXED_OVERHEAD_TILES, 1 + FIXED_OVERHEAD_TILES)
+    p_min = max((total + num_parts - 1) // num_parts, 1 + FIXED_OVERHEAD_TILES)
+    payload = p_min + FIXED_OVERHEAD_TILES
+    for cand in range(p_min, p_min + 64):
+        if _parts_needed(ntiles, cand, num_parts) <= num_parts:
+            payload = cand
+            break
     meta = np.zeros((num_parts, META_W), dtype=np.int32)
     num_splits = np.zeros(bs + 1, dtype=np.int32)
     req, tile, split, cum = 0, 0, 0, 0

@@ -45,6 +45,14 @@ __device__ __forceinline__ uint16_t fl_f32_to_bf16(float f) {
   const uint32_t n = (u >> 16) | 0x40u;
   return (uint16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? n : r);   // branch-free select
 }
+// two f32 -> packed bf16 pair (lo = a), hardware RNE (v_cvt_pk_bf16_f32; same rounding as fl_f32_to_bf16 / torch)
+typedef __bf16 fl_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float fl_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t fl_pack_bf16(float a, float b) {
+  union { fl_bf16x2 h; uint32_t u; } x;
+  x.h = __builtin_convertvector(fl_f32x2{a, b}, fl_bf16x2);
+  return x.u;
+}
 // f32 -> OCP e4m3fn byte, RNE, |x| must be <= 448 (v_cvt_pk_fp8_f32 does not saturate: >464 -> NaN)
 __device__ __forceinline__ uint32_t fl_cvt_pk_fp8(float a, float b) {
   return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
@@ -56,4 +64,22 @@ __device__ __forceinline__ float fl_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
+}
+
+// HBM -> LDS DMA (global_load_lds) as inline asm: lane i of the wave lands at lds_dst + 16 i (4 i); lds_dst must be
+// wave-uniform.  NOT through __builtin_amdgcn_global_load_lds: hipcc's waitcnt pass books the builtin as a FLAT access
+// that touches LDS ("pending flat") and, until a vmcnt(0) OF ITS OWN retires it, forces every later
+// s_waitcnt lgkmcnt(N) to N = 0 — in a pipelined loop whose vmcnt waits are explicit, every LDS operand read then also
+// waits for the reads issued after it.  The asm hides the DMA from the pass; completion is certified by the kernels'
+// explicit s_waitcnt vmcnt + barrier.
+__device__ __forceinline__ int fl_lds_addr(const void* lds_dst) {
+  return __builtin_amdgcn_readfirstlane((int)(uintptr_t)lds_dst);   // low half of a generic LDS pointer = LDS offset
+}
+__device__ __forceinline__ void fl_dma16(const void* gsrc, const void* lds_dst) {   // per-lane 64-bit source
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(fl_lds_addr(lds_dst)), "v"(gsrc)
+               : "memory", "m0");
+}
+__device__ __forceinline__ void fl_dma4(const void* gsrc, const void* lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(fl_lds_addr(lds_dst)), "v"(gsrc)
+               : "memory", "m0");
 }

@@ -96,13 +96,13 @@ __device__ __forceinline__ void kblock_body(v16f (&acc)[MT], const uint8_t* __re
   if (issue) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)   // W: 16 pieces of 8 rows x 128 B; this wave fills pieces 4*wave + k
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_w[k] + k_off), (lds_ptr_t)(dma_w + (wave * 4 + k) * 1024), 16, 0, 0);
+      fl_dma16(src_w[k] + k_off, dma_w + (wave * 4 + k) * 1024);
 #pragma unroll
     for (int k = 0; k < MT; ++k)  // A: 4*MT pieces; this wave fills pieces wave*MT + k
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_a[k] + k_off), (lds_ptr_t)(dma_a + (wave * MT + k) * 1024), 16, 0, 0);
+      fl_dma16(src_a[k] + k_off, dma_a + (wave * MT + k) * 1024);
 #pragma unroll
     for (int k = 0; k < kAsPieces; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_as[k] + as_off), (lds_ptr_t)(dma_as + k * 64), 4, 0, 0);
+      fl_dma4(src_as[k] + as_off, dma_as + k * 64);
   }
   // ---- operands: 4 + 4*MT ds_read_b128 in flight, then the MFMAs ----
   const uint8_t* wp = rd_w + wave * (32 * BK);
@@ -236,16 +236,13 @@ __global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void g
     const int st = kb % kStages;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc[k] + (long long)kb * BK), (lds_ptr_t)(stage_w(st) + (wave * 4 + k) * 1024),
-                                       16, 0, 0);
+      fl_dma16(wsrc[k] + (long long)kb * BK, stage_w(st) + (wave * 4 + k) * 1024);
 #pragma unroll
     for (int k = 0; k < MT; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[k] + (long long)kb * BK),
-                                       (lds_ptr_t)(stage_a(st) + (wave * MT + k) * 1024), 16, 0, 0);
+      fl_dma16(asrc[k] + (long long)kb * BK, stage_a(st) + (wave * MT + k) * 1024);
 #pragma unroll
     for (int k = 0; k < kAsPieces; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(assrc[k] + (long long)kb * p.as_stride_k),
-                                       (lds_ptr_t)(stage_as(st) + k * 64), 4, 0, 0);
+      fl_dma4(assrc[k] + (long long)kb * p.as_stride_k, stage_as(st) + k * 64);
   };
 
   // ---- prologue: stages 0 .. kStages-2 ----

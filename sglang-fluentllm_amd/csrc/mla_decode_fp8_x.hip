@@ -41,6 +41,12 @@ static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
 constexpr int kNopePerWave = kDmaNopePerTile / kNW;             // 8 LDS-DMA pieces of 1 KiB per wave per page
 constexpr float kMaxUp = 100.f;                                 // largest block-scale exponent above the O reference
+#ifndef FL_X_INPLACE
+#define FL_X_INPLACE 0   // 1: lane constants opaque in place (9 fewer v_mov per step, but hipcc then spills Q fragments)
+#endif
+#ifndef FL_X_KAHEAD
+#define FL_X_KAHEAD 2
+#endif
 #ifndef FL_X_OVERLAP
 #define FL_X_OVERLAP true    // softmax of block 0 inside the QK MFMA chain of block 1 (register pressure!)
 #endif
@@ -48,17 +54,19 @@ constexpr float kMaxUp = 100.f;                                 // largest block
 #ifdef FL_MLA_TIMING
 __device__ int* g_dbg_x = nullptr;   // debug builds only: set by fl_mla_debug_set_buffer_x
 #define FL_T(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); tacc[i] += t__ - tlast; tlast = t__; } while (0)
-#define FL_T_PARAMS , unsigned long long (&tacc)[8], unsigned long long& tlast
+#define FL_TV(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); if (i) tacc[i] += t__ - tvar; tvar = t__; } while (0)
+#define FL_T_PARAMS , unsigned long long (&tacc)[16], unsigned long long& tlast
 #define FL_T_ARGS , tacc, tlast
 #else
 #define FL_T(i) do { } while (0)
+#define FL_TV(i) do { } while (0)
 #define FL_T_PARAMS
 #define FL_T_ARGS
 #endif
 
 struct LaneConst {
   int lane, li, lh;
-  int kb[4];       // K operand: byte offset inside a slot for k-step s&3, first 16 B (second: ^16); + (s>>2)*256; + b*16384
+  int kb0;         // K operand: byte offset inside a slot for k-step 0, first 16 B (second: ^16); k-step s: ^ ((s&3) << 6), + (s>>2)*256; + b*16384
   int rb0;         // rope operand, k-step 0 (k-step s: ^ (s << 5); FMT 1 second half: ^16)
   int vb0;         // V^T tr8 source of tile jb = 0 (tile jb: ^ ((jb&3) << 4) ^ ((jb>>2) << 7)); + u immediates; + dh*256
   unsigned dn_row; // latent DMA: byte offset of this lane's token row of piece 0 of this wave
@@ -66,12 +74,29 @@ struct LaneConst {
   unsigned dr[2];
 };
 
+// Online softmax of one S^T block on y = s*log2e + log2(k_scale[t]) (folds the per-token V scale into P), in chunks.
+// Lane (li, lh) holds query row li and tokens 32b + 8g + 4lh + e.  Result: 16 fp8 weights P' = 2^(y - m + 8).
+struct Soft {
+  v16f y;
+  float4 a4[4], b4[3];   // a4[g]: k_scale of group g, later 1/k_scale; b4[g % 3]: log2 k_scale of group g
+  float tmax, moff;
+  int pk[4];
+};
+#ifndef FL_X_C0QK
+#define FL_X_C0QK 12
+#endif
+#ifndef FL_X_C1PV
+#define FL_X_C1PV 10
+#endif
+constexpr int kC0UnderQK = FL_X_C0QK;   // softmax pieces of block 0 under QK block 1 (slots -1..10); the rest under PV
+constexpr int kC1UnderPV = FL_X_C1PV;   // softmax pieces of block 1 under PV; the rest under the next page's QK block 0
+
 struct ReqState {
   v16f o[16];            // O^T: tile dh*8 + jb
   float l[2], lq[2];     // exact / rounded-weight normalisers per block, relative to mw[b]
   float mw[2];           // integer softmax references per block
   float mo;              // reference of O (fixed once set)
-  v16f s1;               // S^T block 1 of the newest page (softmax pending: it runs under the next page's QK block 0)
+  Soft c1;               // softmax of block 1 of the newest page, kC1UnderPV pieces done (rest: next page's QK block 0)
   uint4 p0;              // fp8 weights of block 0 of the newest page (PV pending)
   int redo;              // a block reference outran mo by more than kMaxUp: repeat the request with mo preset
 };
@@ -84,10 +109,10 @@ struct ReqState {
 
 // K operand (A side) of QK k-step s of block b: token 32b + li, 32 B at d = 64s + 32lh
 struct KOp { uint4 lo, hi; };
-__device__ __forceinline__ KOp k_load(const LaneConst& lc, const uint8_t* __restrict__ kp, const int s) {
-  KOp r;
-  r.lo = *reinterpret_cast<const uint4*>(kp + lc.kb[s & 3] + (s >> 2) * 256);
-  r.hi = *reinterpret_cast<const uint4*>(kp + (lc.kb[s & 3] ^ 16) + (s >> 2) * 256);
+__device__ __forceinline__ KOp k_load(const int (&kbk)[4], const uint8_t* __restrict__ kp, const int s) {
+  KOp r;   // (k-steps s and s + 4 share their two addresses: + 256 is a ds_read immediate)
+  r.lo = *reinterpret_cast<const uint4*>(kp + kbk[s & 3] + (s >> 2) * 256);
+  r.hi = *reinterpret_cast<const uint4*>(kp + (kbk[s & 3] ^ 16) + (s >> 2) * 256);
   return r;
 }
 
@@ -135,15 +160,6 @@ __device__ __forceinline__ void mfma_fp8(v16f& acc, const v8i a, const v8i b) {
 }
 #define FL_MFMA_DRAIN() asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory")
 
-// Online softmax of one S^T block on y = s*log2e + log2(k_scale[t]) (folds the per-token V scale into P), in chunks.
-// Lane (li, lh) holds query row li and tokens 32b + 8g + 4lh + e.  Result: 16 fp8 weights P' = 2^(y - m + 8).
-struct Soft {
-  v16f y;
-  float4 a4[4], b4[3];   // a4[g]: k_scale of group g, later 1/k_scale; b4[g % 3]: log2 k_scale of group g
-  float tmax, moff;
-  int pk[4];
-};
-constexpr int kSoftChunks = 10;
 // Every LDS read of the softmax is issued TWO chunks (MFMA slots) before its first use: the LDS round trip is ~140
 // cycles unloaded, more than one 64-cycle slot.
 __device__ __forceinline__ void sm_load_kl(Soft& c, const float* __restrict__ scr, const int g, const int b,
@@ -185,32 +201,30 @@ __device__ __forceinline__ void sm_ref(Soft& c, float& m_w, float& l_run, float&
   m_w = m_new;
   c.moff = kPShift - m_new;
   asm volatile("" : "+v"(l_run), "+v"(lq_run), "+v"(m_w), "+v"(c.moff));   // pin (see sm_scale)
+  // unspecified start values for the packed weights (v_cvt_pk_fp8_f32 writes half a register and keeps the other half:
+  // a defined 0 costs a v_mov per group)
+  asm volatile("" : "=v"(c.pk[0]), "=v"(c.pk[1]), "=v"(c.pk[2]), "=v"(c.pk[3]));
 }
-__device__ __forceinline__ void sm_exp(Soft& c, const int g, float& l_run, float& lq_run) {
-  const float e0 = __builtin_amdgcn_exp2f(c.y[g * 4 + 0] + c.moff);
-  const float e1 = __builtin_amdgcn_exp2f(c.y[g * 4 + 1] + c.moff);
-  const float e2 = __builtin_amdgcn_exp2f(c.y[g * 4 + 2] + c.moff);
-  const float e3 = __builtin_amdgcn_exp2f(c.y[g * 4 + 3] + c.moff);
-  l_run = fmaf(e0, c.a4[g].x, l_run);   // unrounded sum: exact LSE
-  l_run = fmaf(e1, c.a4[g].y, l_run);
-  l_run = fmaf(e2, c.a4[g].z, l_run);
-  l_run = fmaf(e3, c.a4[g].w, l_run);
-  const int v = __builtin_amdgcn_cvt_pk_fp8_f32(e0, e1, 0, false);
-  c.pk[g] = __builtin_amdgcn_cvt_pk_fp8_f32(e2, e3, v, true);
+// half h (elements 2h, 2h+1) of group g: the unit that fits beside one 64-cycle MFMA
+__device__ __forceinline__ void sm_exp_half(Soft& c, const int g, const int h, float& l_run, float& lq_run) {
+  const float e0 = __builtin_amdgcn_exp2f(c.y[g * 4 + 2 * h + 0] + c.moff);
+  const float e1 = __builtin_amdgcn_exp2f(c.y[g * 4 + 2 * h + 1] + c.moff);
+  const float k0 = h ? c.a4[g].z : c.a4[g].x, k1 = h ? c.a4[g].w : c.a4[g].y;
+  l_run = fmaf(e0, k0, l_run);   // unrounded sum: exact LSE
+  l_run = fmaf(e1, k1, l_run);
+  c.pk[g] = h ? __builtin_amdgcn_cvt_pk_fp8_f32(e0, e1, c.pk[g], true) : __builtin_amdgcn_cvt_pk_fp8_f32(e0, e1, c.pk[g], false);
   // the ROUNDED weights normalise O (numerator and denominator use the same weights: they sum to exactly 1)
-  const float2v d01 = __builtin_amdgcn_cvt_pk_f32_fp8(c.pk[g], false);
-  const float2v d23 = __builtin_amdgcn_cvt_pk_f32_fp8(c.pk[g], true);
-  lq_run = fmaf(d01[0], c.a4[g].x, lq_run);
-  lq_run = fmaf(d01[1], c.a4[g].y, lq_run);
-  lq_run = fmaf(d23[0], c.a4[g].z, lq_run);
-  lq_run = fmaf(d23[1], c.a4[g].w, lq_run);
+  const float2v d = h ? __builtin_amdgcn_cvt_pk_f32_fp8(c.pk[g], true) : __builtin_amdgcn_cvt_pk_f32_fp8(c.pk[g], false);
+  lq_run = fmaf(d[0], k0, lq_run);
+  lq_run = fmaf(d[1], k1, lq_run);
   asm volatile("" : "+v"(l_run), "+v"(lq_run), "+v"(c.pk[g]));   // pin (see sm_scale)
 }
-// chunk k (0..9) of a block's softmax:
-//   0: loads {ks, lk}(0), (1)      1: scale 0, loads (2)      2: scale 1, loads (3)      3: scale 2      4: scale 3, ik(0)
-//   5: reference, ik(1)            6: exp 0, ik(2)            7: exp 1, ik(3)            8: exp 2        9: exp 3
+// piece k (0..13) of a block's softmax; every LDS read is issued two or more pieces before its first use:
+//   0: loads {ks, lk}(0), (1)     1..4: scale g = k-1 (+ loads (k+1) for k <= 2, ik(0) at k = 4)     5: reference, ik(1)
+//   6 + 2g + h: exp of half h of group g (+ ik(g + 2) at h = 0, g < 2)
+constexpr int kSoftPieces = 14;
 template <int DUMMY = 0>
-__device__ __forceinline__ void sm_chunk(Soft& c, const int k, const float* __restrict__ scr, const int b, const int lh,
+__device__ __forceinline__ void sm_piece(Soft& c, const int k, const float* __restrict__ scr, const int b, const int lh,
                                          const float qs, const int tok0, const int L_row, const bool need_mask,
                                          float& m_w, float& l_run, float& lq_run) {
   if (k == 0) {
@@ -224,32 +238,35 @@ __device__ __forceinline__ void sm_chunk(Soft& c, const int k, const float* __re
   } else if (k == 5) {
     sm_ref(c, m_w, l_run, lq_run);
     sm_load_ik(c, scr, 1, b, lh);
-  } else if (k < kSoftChunks) {
-    if (k <= 7) sm_load_ik(c, scr, k - 4, b, lh);
-    sm_exp(c, k - 6, l_run, lq_run);
+  } else if (k < kSoftPieces) {
+    const int g = (k - 6) >> 1, h = (k - 6) & 1;
+    if (h == 0 && g < 2) sm_load_ik(c, scr, g + 2, b, lh);
+    sm_exp_half(c, g, h, l_run, lq_run);
   }
 }
 
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 
-template <int FMT, bool SOFT, class Hook = NoHook>
+// One QK block: 4 rope slots (FMT 0; one fp8 slot for FMT 1) + 8 latent slots.  hook(-1) runs before the first MFMA,
+// hook(s), s = 0..11, inside slot s AFTER its MFMA and operand reads — the overlapped softmax pieces / LDS-DMA issue.
+template <int FMT, class Hook = NoHook>
 __device__ __forceinline__ v16f qk_stage(const LaneConst& lc, const uint8_t* __restrict__ k_nope,
                                          const uint8_t* __restrict__ k_rope, const int b, const v8i (&qn)[8],
-                                         const v8bf (&qr)[4], const v8i qr8, Soft& c, const float* __restrict__ scr,
-                                         const int sb_, const int lh, const float qs, const int tok0, const int L_row,
-                                         const bool need_mask, float& m_w, float& l_run, float& lq_run,
-                                         const Hook& hook = Hook()) {
+                                         const v8bf (&qr)[4], const v8i qr8, const Hook& hook = Hook()) {
   const uint8_t* kp = k_nope + b * (32 * kDN);
   const uint8_t* rp = k_rope + b * (32 * (FMT == 0 ? kDR * 2 : kDR));
   uint4 ra[4];
   ra[0] = *reinterpret_cast<const uint4*>(rp + lc.rb0);
   ra[1] = *reinterpret_cast<const uint4*>(rp + (lc.rb0 ^ (FMT == 0 ? 32 : 16)));
-  KOp ka[4];   // operands are read THREE slots ahead of their MFMA (LDS round trip ~140+ cycles under load)
-  ka[0] = k_load(lc, kp, 0);
-  if constexpr (SOFT) sm_chunk(c, 0, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
+  constexpr int kAhead = FL_X_KAHEAD;   // latent operands are read kAhead slots before their MFMA (LDS round trip ~140+ cycles)
+  KOp ka[kAhead + 1];
+  int kb0 = lc.kb0;   // opaque per stage: the three derived k-step offsets are not kept live across stages (spills)
+  asm volatile("" : "+v"(kb0));
+  const int kbk[4] = {kb0, kb0 ^ 64, kb0 ^ 128, kb0 ^ 192};
+  ka[0] = k_load(kbk, kp, 0);
+  hook(-1);
   FL_SLOT_END();
   v16f acc;
-  int chunk = 1;
   if constexpr (FMT == 0) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -259,32 +276,22 @@ __device__ __forceinline__ v16f qk_stage(const LaneConst& lc, const uint8_t* __r
       if (s == 0) mfma_rope_first(acc, ra[s], qr[s]);
       else mfma_rope(acc, ra[s], qr[s]);
       if (s < 2) ra[s + 2] = *reinterpret_cast<const uint4*>(rp + (lc.rb0 ^ ((s + 2) << 5)));
-      if (s == 1) ka[1] = k_load(lc, kp, 1);
-      if (s == 3) ka[2] = k_load(lc, kp, 2);
-      if (SOFT && (s & 1)) { sm_chunk(c, chunk, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run); ++chunk; }
+      if (s == 1) ka[1] = k_load(kbk, kp, 1);
+      if (s == 3 && kAhead == 3) ka[2] = k_load(kbk, kp, 2);
       hook(s);
       FL_SLOT_END();
     }
   } else {
-    ka[1] = k_load(lc, kp, 1);
-    ka[2] = k_load(lc, kp, 2);
+    ka[1] = k_load(kbk, kp, 1);
+    if (kAhead == 3) ka[2] = k_load(kbk, kp, 2);
     mfma_fp8_first(acc, make_v8i(ra[0], ra[1]), qr8);
-    if constexpr (SOFT) {
-      sm_chunk(c, 1, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
-      sm_chunk(c, 2, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
-      chunk = 3;
-    }
     hook(0); hook(1); hook(2); hook(3);
     FL_SLOT_END();
   }
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
-    mfma_fp8(acc, make_v8i(ka[s % 4].lo, ka[s % 4].hi), qn[s]);
-    if (s + 3 < 8) ka[(s + 3) % 4] = k_load(lc, kp, s + 3);
-    if (SOFT && chunk < kSoftChunks) {
-      sm_chunk(c, chunk, scr, sb_, lh, qs, tok0, L_row, need_mask, m_w, l_run, lq_run);
-      ++chunk;
-    }
+    mfma_fp8(acc, make_v8i(ka[s % (kAhead + 1)].lo, ka[s % (kAhead + 1)].hi), qn[s]);
+    if (s + kAhead < 8) ka[(s + kAhead) % (kAhead + 1)] = k_load(kbk, kp, s + kAhead);
     hook(4 + s);
     FL_SLOT_END();
   }
@@ -292,12 +299,39 @@ __device__ __forceinline__ v16f qk_stage(const LaneConst& lc, const uint8_t* __r
   return acc;
 }
 
+// HBM -> LDS DMA as inline asm.  Through the builtin, hipcc's waitcnt pass sees a FLAT instruction that touches LDS
+// ("pending flat"): until a vmcnt(0) retires it, EVERY lgkmcnt wait is forced to 0 — and the page loop never drains
+// vmcnt, so each ds_read wait also waited for the operand reads issued just before it (~140+ cycles, several times per
+// stage).  The asm hides the DMA from the pass; its completion is certified by the explicit vmcnt waits + barrier of
+// page_step.  M0 = LDS base of the wave's 1-KiB piece (lane i lands at base + 16 i / 4 i).
+__device__ __forceinline__ void dma_x4(const uint8_t* sbase, const unsigned voff, const uint8_t* lds_dst) {
+#ifdef FL_X_DMA_BUILTIN
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sbase + voff), (lds_ptr_t)(const_cast<uint8_t*>(lds_dst)), 16, 0, 0);
+  return;
+#endif
+  const int la = __builtin_amdgcn_readfirstlane((int)(uintptr_t)lds_dst);   // low half of a generic LDS pointer = offset
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la), "v"(voff), "s"(sbase)
+               : "memory", "m0");
+}
+__device__ __forceinline__ void dma_x1(const float* sbase, const unsigned voff, const float* lds_dst) {
+#ifdef FL_X_DMA_BUILTIN
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const uint8_t*>(sbase) + voff), (lds_ptr_t)(const_cast<float*>(lds_dst)), 4, 0, 0);
+  return;
+#endif
+  const int la = __builtin_amdgcn_readfirstlane((int)(uintptr_t)lds_dst);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(la), "v"(voff), "s"(sbase)
+               : "memory", "m0");
+}
+
 // Copy of the lane constants that the optimiser cannot see through: everything derived from it stays where it is used
 // instead of being hoisted (LICM) into dozens of long-lived registers.
+__device__ __forceinline__ void opaque_inplace(LaneConst& lc) {
+  asm volatile("" : "+v"(lc.lane), "+v"(lc.li), "+v"(lc.lh), "+v"(lc.kb0), "+v"(lc.rb0), "+v"(lc.vb0), "+v"(lc.dn_row),
+               "+v"(lc.dn_x), "+v"(lc.dr[0]), "+v"(lc.dr[1]));
+}
 __device__ __forceinline__ LaneConst opaque(const LaneConst& in) {
   LaneConst lc = in;
-  asm volatile("" : "+v"(lc.lane), "+v"(lc.li), "+v"(lc.lh), "+v"(lc.kb[0]), "+v"(lc.kb[1]), "+v"(lc.kb[2]),
-               "+v"(lc.kb[3]), "+v"(lc.rb0), "+v"(lc.vb0), "+v"(lc.dn_row), "+v"(lc.dn_x), "+v"(lc.dr[0]),
+  asm volatile("" : "+v"(lc.lane), "+v"(lc.li), "+v"(lc.lh), "+v"(lc.kb0), "+v"(lc.rb0), "+v"(lc.vb0), "+v"(lc.dn_row), "+v"(lc.dn_x), "+v"(lc.dr[0]),
                "+v"(lc.dr[1]));
   return lc;
 }
@@ -321,7 +355,7 @@ __device__ __forceinline__ unsigned dn_off(const LaneConst& lc, const int k) {
 // queue with vmcnt(0) before every ds_read).
 template <int FMT, bool has_cur, bool has_prev, bool FAST>
 __device__ __forceinline__ void page_step(
-    ReqState& st, const LaneConst& lc_in, const v8i (&qn)[8], const v8bf (&qr)[4], const v8i qr8, const float qs,
+    ReqState& st, LaneConst& lc_io, const v8i (&qn)[8], const v8bf (&qr)[4], const v8i qr8, const float qs,
     const float ks_const, const int wave,
     // ---- page i: latent slot, rope slot, raw scales; wave-private triple scratch
     const uint8_t* __restrict__ k_nope, const uint8_t* __restrict__ k_rope, const float* __restrict__ k_scale_raw,
@@ -342,7 +376,14 @@ __device__ __forceinline__ void page_step(
   const bool need_mask = FAST ? false : need_mask_rt;
   const bool need_mask_prev = FAST ? false : need_mask_prev_rt;
   const bool next_in_flight = FAST ? true : next_in_flight_rt;
-  const LaneConst lc = opaque(lc_in);
+  // the lane constants are made opaque IN PLACE: to the optimiser they are loop-carried values that change every step
+  // (nothing derived from them is hoisted, and no per-step copies of the originals are kept alive beside them)
+#if FL_X_INPLACE
+  opaque_inplace(lc_io);
+  const LaneConst& lc = lc_io;
+#else
+  const LaneConst lc = opaque(lc_io);
+#endif
   const int lane = lc.lane, li = lc.li, lh = lc.lh;
 
   // ---- page i landed for every wave (issue order per step: rope, scale, latent of ONE page); every wave is done with
@@ -364,14 +405,12 @@ __device__ __forceinline__ void page_step(
   const bool do_dma = FAST ? true : (src_nope != nullptr);
   auto dma_piece = [&](const int k) {   // k = 0 .. kRopePerWave + (FMT == 0) + kNopePerWave - 1
     if (k < kRopePerWave) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_rope + lc.dr[k < kRopePerWave ? k : 0]),
-                                       (lds_ptr_t)(dma_rope + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
+      dma_x4(src_rope, lc.dr[k < kRopePerWave ? k : 0], dma_rope + (wave * kRopePerWave + k) * 1024);
     } else if (FMT == 0 && k == kRopePerWave) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
+      dma_x1(src_scale, (unsigned)lane * 4u, dma_scale);
     } else {
       const int kk = k - kRopePerWave - (FMT == 0 ? 1 : 0);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_nope + dn_off<FMT>(lc, kk)),
-                                       (lds_ptr_t)(dma_nope + (wave * kNopePerWave + kk) * 1024), 16, 0, 0);
+      dma_x4(src_nope, dn_off<FMT>(lc, kk), dma_nope + (wave * kNopePerWave + kk) * 1024);
     }
   };
   constexpr int kPieces = kRopePerWave + (FMT == 0 ? 1 : 0) + kNopePerWave;   // 11 / 9: fits the 12 (9) slots
@@ -382,9 +421,18 @@ __device__ __forceinline__ void page_step(
     }
   }
 
-  // c1: block 1 of page i-1 (its S^T was left in st.s1 by the previous step); c0: block 0 of page i
-  Soft c0, c1;
-  c1.y = st.s1;
+  // c1: block 1 of page i-1 — its first kC1UnderPV softmax pieces ran under the PV MFMAs of the previous step (state in
+  // st.c1), the rest runs here under QK block 0.  c0: block 0 of page i.  c1n: block 1 of page i.
+  Soft c0, c1 = st.c1, c1n;
+  auto c1_piece = [&](const int k) {
+    sm_piece(c1, k, scr_prev, 1, lh, qs, tok0 - kPage, L_row, need_mask_prev, st.mw[1], st.l[1], st.lq[1]);
+  };
+  auto c0_piece = [&](const int k) {
+    sm_piece(c0, k, scr, 0, lh, qs, tok0, L_row, need_mask, st.mw[0], st.l[0], st.lq[0]);
+  };
+  auto c1n_piece = [&](const int k) {
+    sm_piece(c1n, k, scr, 1, lh, qs, tok0, L_row, need_mask, st.mw[1], st.l[1], st.lq[1]);
+  };
   if constexpr (has_cur) {
     float ks_raw = ks_const;
     if constexpr (FMT == 0) ks_raw = k_scale_raw[lane];   // consumed two slots later
@@ -408,17 +456,23 @@ __device__ __forceinline__ void page_step(
         scr[2 * kPage + lane] = __builtin_amdgcn_rcpf(ks);
       }
       constexpr int kSlots = FMT == 0 ? 12 : 9;
-      if (do_dma && slot < kSlots && slot < kPieces) dma_piece(slot);
+      if (slot >= 0 && do_dma && slot < kSlots && slot < kPieces) dma_piece(slot);
+      // remaining pieces of block 1 of page i-1 in the 64-cycle latent slots
+      if constexpr (has_prev) {
+        constexpr int kRest = kSoftPieces - kC1UnderPV;
+        static_assert(kRest <= 8, "QK block 0 has 8 latent slots for the tail of block 1");
+        constexpr int kStride = kRest <= 4 ? 2 : 1;
+        if (slot >= 4 && (slot - 4) % kStride == 0 && (slot - 4) / kStride < kRest)
+          c1_piece(kC1UnderPV + (slot - 4) / kStride);
+      }
     };
-    // ---- A. QK block 0 of page i || softmax of block 1 of page i-1; QK block 1 of page i || softmax of block 0 ----
-    c0.y = qk_stage<FMT, has_prev>(lc, k_nope, k_rope, 0, qn, qr, qr8, c1, scr_prev, 1, lh, qs, tok0 - kPage, L_row,
-                                  need_mask_prev, st.mw[1], st.l[1], st.lq[1], hook);
+    // ---- A. QK block 0 of page i || tail of the softmax of block 1 of page i-1 ----
+    c0.y = qk_stage<FMT>(lc, k_nope, k_rope, 0, qn, qr, qr8, hook);
     FL_SLOT_END();
     FL_T(2);   // QK block 0 || softmax 1 of the previous page
   } else {
 #pragma unroll
-    for (int k = 0; k < kSoftChunks; ++k)
-      sm_chunk(c1, k, scr_prev, 1, lh, qs, tok0 - kPage, L_row, need_mask_prev, st.mw[1], st.l[1], st.lq[1]);
+    for (int k = kC1UnderPV; k < kSoftPieces; ++k) c1_piece(k);
     FL_SLOT_END();
   }
 
@@ -437,15 +491,23 @@ __device__ __forceinline__ void page_step(
     sb = sb < 0 ? 0 : sb;
     pb = make_v8i(st.p0, make_uint4(c1.pk[0], c1.pk[1], c1.pk[2], c1.pk[3]));
   }
+  // ---- B. QK block 1 of page i || first kC0UnderQK pieces of the softmax of block 0 ----
   if constexpr (has_cur) {
-    st.s1 = qk_stage<FMT, true>(lc, k_nope, k_rope, 1, qn, qr, qr8, c0, scr, 0, lh, qs, tok0, L_row, need_mask, st.mw[0],
-                               st.l[0], st.lq[0]);
-    st.p0 = make_uint4(c0.pk[0], c0.pk[1], c0.pk[2], c0.pk[3]);
+    c1n.y = qk_stage<FMT>(lc, k_nope, k_rope, 1, qn, qr, qr8, [&](const int slot) {
+      if (slot + 1 < kC0UnderQK) c0_piece(slot + 1);
+    });
     FL_SLOT_END();
     FL_T(3);   // QK block 1 || softmax 0
   }
 
-  // ---- C. O^T += V^T(i-1) · P^T(i-1): nothing but the MFMA touches O in the page loop ----
+  // ---- C. O^T += V^T(i-1) · P^T(i-1) || rest of block 0 and first kC1UnderPV pieces of block 1 of page i.  Nothing but
+  //      the MFMA touches O in the page loop. ----
+  auto pv_piece = [&](const int t) {   // t = 0 .. 15
+    constexpr int kC0Rest = kSoftPieces - kC0UnderQK;
+    if (t < kC0Rest) c0_piece(kC0UnderQK + t);
+    else if (t - kC0Rest < kC1UnderPV) c1n_piece(t - kC0Rest);
+  };
+  static_assert(kSoftPieces - kC0UnderQK + kC1UnderPV <= 16, "PV has 16 slots");
   if constexpr (has_prev) {
     v8i va[4];
     va[0] = vt_load(lc, v_nope, 0);
@@ -456,8 +518,19 @@ __device__ __forceinline__ void page_step(
     for (int t = 0; t < 16; ++t) {
       if (t + 3 < 16) va[(t + 3) % 4] = vt_load(lc, v_nope, t + 3);
       st.o[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[t % 4], pb, st.o[t], 0, 0, 0, kUnitScale, 0, sb);
+      if constexpr (has_cur) pv_piece(t);
       FL_SLOT_END();
     }
+  } else if constexpr (has_cur) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      pv_piece(t);
+      FL_SLOT_END();
+    }
+  }
+  if constexpr (has_cur) {
+    st.p0 = make_uint4(c0.pk[0], c0.pk[1], c0.pk[2], c0.pk[3]);
+    st.c1 = c1n;
   }
   FL_T(4);   // PV
 }
@@ -485,9 +558,7 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     LaneConst& lc = lc0;
     const int li = lc.li, lh = lc.lh, lane = lc.lane;
     const int kx = li & 15;
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2)
-      lc.kb[k2] = li * kDN + (((((k2 ^ (kx >> 2)) << 2) | ((2 * lh) ^ (kx & 3))) << 4));
+    lc.kb0 = li * kDN + (((((kx >> 2)) << 2) | ((2 * lh) ^ (kx & 3))) << 4);
     if constexpr (FMT == 0) lc.rb0 = li * (kDR * 2) + (((lh ^ ((li >> 1) & 7))) << 4);
     else lc.rb0 = li * kDR + ((((2 * lh) ^ ((li >> 2) & 3))) << 4);
     const int s16 = lane & 15;
@@ -514,7 +585,11 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
 
   // ---- workgroup -> (part, row group) ----
   const int rgrp = blockIdx.x % p.row_groups;
+#ifdef FL_X_SWAP
+  const int part = (blockIdx.x / p.row_groups) ^ 1;
+#else
   const int part = blockIdx.x / p.row_groups;
+#endif
   const int32_t* meta = g_meta + part * FL_MLA_META_W;
   int req = meta[0];
   int tile_b = meta[1];
@@ -523,8 +598,9 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
   int split_idx = meta[4];
 
 #ifdef FL_MLA_TIMING
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_readcyclecounter();
+  unsigned long long tvar = tlast;
   const unsigned long long tstart = tlast;
 #endif
   const int row = rgrp * (32 * kNW) + wave * 32 + li;   // query row of this lane
@@ -556,6 +632,7 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     // every wave finished with the LDS of the previous request (and its stores left the vmcnt queue)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    FL_T(8);   // prologue: scheduler row, lengths, page window
 
     auto src_nope_of = [&](int t) { return g_k_nope + page_of(t) * (kPage * kTokBytes); };
     auto src_rope_of = [&](int t) {
@@ -576,18 +653,17 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
       const uint8_t* sr = src_rope_of(t);
 #pragma unroll
       for (int k = 0; k < kRopePerWave; ++k)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sr + lc.dr[k]),
-                                         (lds_ptr_t)(rope_slot(t) + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
+        dma_x4(sr, lc.dr[k], rope_slot(t) + (wave * kRopePerWave + k) * 1024);
       if constexpr (FMT == 0)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale_of(t) + lane), (lds_ptr_t)scale_slot(t), 4, 0, 0);
+        dma_x1(src_scale_of(t), (unsigned)lane * 4u, scale_slot(t));
       const uint8_t* sn = src_nope_of(t);
 #pragma unroll
       for (int k = 0; k < kNopePerWave; ++k)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sn + dn_off<FMT>(lc, k)),
-                                         (lds_ptr_t)(ring(t) + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
+        dma_x4(sn, dn_off<FMT>(lc, k), ring(t) + (wave * kNopePerWave + k) * 1024);
     };
     if (n > 0) dma_page(0);
     if (n > 1) dma_page(1);
+    FL_T(9);   // prologue: DMA issue of pages 0 and 1
 
     // ---- Q fragments (B operands), once per request ----
     const long long qrow = (long long)req * p.rows + row;
@@ -625,6 +701,7 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     if (!row_ok) L_row = 0;
     const int L_min = p.causal ? L - (p.s_q - 1) : L;
 
+    FL_T(10);  // prologue: Q loads
     ReqState st;
     float mo_preset = kNegRef;
     // pass 0 fixes the O reference at each row's first valid page; pass 1 runs only if some block reference outran it
@@ -641,8 +718,7 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     st.mo = mo_preset;
     st.redo = 0;
     st.p0 = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st.s1[r] = 0.f;
+    st.c1 = Soft{};
 
     if (pass == 1) {   // (pass 0 issued its prologue before the Q loads)
       load_window(0);
@@ -672,13 +748,18 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     FL_T(7);   // request prologue (window, DMA of pages 0/1, Q loads, O init)
     if (n > 0) {
       int i = 0;
+      FL_TV(0);
       FL_STEP(true, false, false);
+      FL_TV(12);   // whole first step
       // steady state: pages i-1, i unmasked for every row and page i+2 present
       int n_fast = L_min / kPage - tile_b;
       n_fast = n_fast < n - 2 ? n_fast : n - 2;
       for (i = 1; i < n_fast; ++i) FL_STEP(true, true, true);
+      FL_TV(13);   // all FAST steps
       for (; i < n; ++i) FL_STEP(true, true, false);
+      FL_TV(14);   // generic steps
       FL_STEP(false, true, false);
+      FL_TV(15);   // last step
     }
 #undef FL_STEP
     if (pass == 1) break;
@@ -725,6 +806,7 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     // 256-B bf16 row segments (final output, or the split partial of this part).
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // every wave is past its last K / V^T read
+    FL_T(11);  // epilogue: normalisers, LSE, barrier
     {
       constexpr int kStgStride = 128 + 4;   // floats per staged row
       // (opaque lane id: keeps the store addresses from being hoisted out of the request loop and spilled)
@@ -757,11 +839,11 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
             const int r = (lane >> 4) + 4 * k;
             const float4 v0 = *reinterpret_cast<const float4*>(stg + r * kStgStride + (lane & 15) * 8);
             const float4 v1 = *reinterpret_cast<const float4*>(stg + r * kStgStride + (lane & 15) * 8 + 4);
-            uint4 o;
-            o.x = (uint32_t)fl_f32_to_bf16(v0.x) | ((uint32_t)fl_f32_to_bf16(v0.y) << 16);
-            o.y = (uint32_t)fl_f32_to_bf16(v0.z) | ((uint32_t)fl_f32_to_bf16(v0.w) << 16);
-            o.z = (uint32_t)fl_f32_to_bf16(v1.x) | ((uint32_t)fl_f32_to_bf16(v1.y) << 16);
-            o.w = (uint32_t)fl_f32_to_bf16(v1.z) | ((uint32_t)fl_f32_to_bf16(v1.w) << 16);
+            uint4 o;   // v_cvt_pk_bf16_f32: RNE, two values per instruction
+            o.x = fl_pack_bf16(v0.x, v0.y);
+            o.y = fl_pack_bf16(v0.z, v0.w);
+            o.z = fl_pack_bf16(v1.x, v1.y);
+            o.w = fl_pack_bf16(v1.z, v1.w);
             if (row0 + r < p.rows) *reinterpret_cast<uint4*>(dbase + (long long)r * kDN) = o;
           }
         }
@@ -774,10 +856,10 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
   }
 #ifdef FL_MLA_TIMING
   if (g_dbg_x != nullptr && lane == 0) {
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(g_dbg_x) + ((long long)blockIdx.x * 4 + wave) * 10;
-    for (int i = 0; i < 8; ++i) d[i] = tacc[i];
-    d[8] = __builtin_readcyclecounter() - tstart;
-    d[9] = tlast - tstart;
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(g_dbg_x) + ((long long)blockIdx.x * 4 + wave) * 18;
+    for (int i = 0; i < 16; ++i) d[i] = tacc[i];
+    d[16] = __builtin_readcyclecounter() - tstart;
+    d[17] = tlast - tstart;
   }
 #endif
 }
