@@ -83,3 +83,12 @@ __device__ __forceinline__ void fl_dma4(const void* gsrc, const void* lds_dst) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(fl_lds_addr(lds_dst)), "v"(gsrc)
                : "memory", "m0");
 }
+// same, with the builtin's argument list (drop-in for __builtin_amdgcn_global_load_lds(g, l, size, 0, 0))
+__device__ __forceinline__ void fl_dma_lds(const __attribute__((address_space(1))) void* gsrc,
+                                           __attribute__((address_space(3))) void* lds_dst, const int size, int, int) {
+  const int la = __builtin_amdgcn_readfirstlane((int)(uintptr_t)lds_dst);
+  if (size == 16)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gsrc) : "memory", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(la), "v"(gsrc) : "memory", "m0");
+}

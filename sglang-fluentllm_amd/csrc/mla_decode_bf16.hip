@@ -52,7 +52,7 @@ __device__ __forceinline__ void tile_body(
   if (dma_src != nullptr) {
 #pragma unroll
     for (int k = 0; k < kPiecesPerWave; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(dma_src + dsrc[k]),
+      fl_dma_lds((gbl_ptr_t)(dma_src + dsrc[k]),
                                        (lds_ptr_t)(dma_dst + (wave * kPiecesPerWave + k) * 1024), 16, 0, 0);
   }
   // tail of the sequence: zero the rows past the end (P is exactly 0 there, but 0*NaN would poison the PV MFMA)
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void mla_decode_bf16_kernel(
       const uint8_t* src = tile_src(t);
 #pragma unroll
       for (int k = 0; k < kPiecesPerWave; ++k)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + dsrc[k]),
+        fl_dma_lds((gbl_ptr_t)(src + dsrc[k]),
                                          (lds_ptr_t)(slot(t) + (wave * kPiecesPerWave + k) * 1024), 16, 0, 0);
     }
     for (int i = 0; i < n; ++i) {

@@ -147,13 +147,13 @@ __device__ __forceinline__ void tile_body(
   __builtin_amdgcn_s_barrier();
   if (src_rope != nullptr) {
     for (int k = 0; k < kRopePerWave; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const uint8_t*>(src_rope) + lc.dr[k]),
+      fl_dma_lds((gbl_ptr_t)(reinterpret_cast<const uint8_t*>(src_rope) + lc.dr[k]),
                                        (lds_ptr_t)(dma_rope + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
+    fl_dma_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
   }
   if (src_nope != nullptr) {
     for (int k = 0; k < kNopePerWave; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_nope + lc.dn[k]),
+      fl_dma_lds((gbl_ptr_t)(src_nope + lc.dn[k]),
                                        (lds_ptr_t)(dma_nope + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
   }
   return;
@@ -354,16 +354,16 @@ __device__ __forceinline__ void tile_body(
     if (jb == 0 && do_rs) {
 #pragma unroll
       for (int k = 0; k < kRopePerWave; ++k)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const uint8_t*>(src_rope) + lc.dr[k]),
+        fl_dma_lds((gbl_ptr_t)(reinterpret_cast<const uint8_t*>(src_rope) + lc.dr[k]),
                                          (lds_ptr_t)(dma_rope + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
       if constexpr (FMT == 0)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
+        fl_dma_lds((gbl_ptr_t)(src_scale + lane), (lds_ptr_t)dma_scale, 4, 0, 0);
     }
     if (do_n) {
       constexpr int kPer = (kNopePerWave + 7) / 8;   // latent pieces issued behind each PV MFMA
 #pragma unroll
       for (int k = jb * kPer; k < (jb + 1) * kPer && k < kNopePerWave; ++k)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_nope + lc.dn[k]),
+        fl_dma_lds((gbl_ptr_t)(src_nope + lc.dn[k]),
                                          (lds_ptr_t)(dma_nope + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
     }
     if (jb == 4 && has_next) {
@@ -580,12 +580,12 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
         uint8_t* dr = smem + kOffRope + (t & 1) * kRopeBytes;
 #pragma unroll
         for (int k = 0; k < kRopePerWave; ++k)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sr + lc.dr[k]), (lds_ptr_t)(dr + (wave * kRopePerWave + k) * 1024),
+          fl_dma_lds((gbl_ptr_t)(sr + lc.dr[k]), (lds_ptr_t)(dr + (wave * kRopePerWave + k) * 1024),
                                            16, 0, 0);
         if constexpr (FMT == 0) {
           const float* ss = g_k_scale + pg * kPage;
           float* ds = reinterpret_cast<float*>(smem + kOffScale + (t & 1) * (kPage * 4));
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ss + lane), (lds_ptr_t)ds, 4, 0, 0);
+          fl_dma_lds((gbl_ptr_t)(ss + lane), (lds_ptr_t)ds, 4, 0, 0);
         }
       };
       auto dma_n = [&](int t) {
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
         uint8_t* dn = smem + kOffRing + (t & 3) * kSlotBytes;
 #pragma unroll
         for (int k = 0; k < kNopePerWave; ++k)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sn + lc.dn[k]), (lds_ptr_t)(dn + (wave * kNopePerWave + k) * 1024),
+          fl_dma_lds((gbl_ptr_t)(sn + lc.dn[k]), (lds_ptr_t)(dn + (wave * kNopePerWave + k) * 1024),
                                            16, 0, 0);
       };
       if (n > 0) { dma_rs(0); dma_n(0); }
