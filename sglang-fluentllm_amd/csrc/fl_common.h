@@ -92,3 +92,8 @@ __device__ __forceinline__ void fl_dma_lds(const __attribute__((address_space(1)
   else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(la), "v"(gsrc) : "memory", "m0");
 }
+// saddr forms: wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset
+__device__ __forceinline__ void fl_dma16_s(const void* sbase, const unsigned voff, const void* lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(fl_lds_addr(lds_dst)), "v"(voff), "s"(sbase)
+               : "memory", "m0");
+}

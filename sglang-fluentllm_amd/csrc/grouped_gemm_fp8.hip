@@ -18,8 +18,10 @@
 // k block.  Tiles of experts with no rows are never scheduled; the grid is an upper bound, surplus blocks exit.
 //
 // Algorithmic bytes / flops per MoE layer: SURVEY.md §8(d) (weights 44.04 MB per expert hit, 88.08 MFLOP per row).
-#include "fl_common.h"
+#include "grouped_gemm_shared.h"
 #include <cstdlib>
+
+using namespace fl_gemm;
 
 namespace {
 
@@ -31,30 +33,6 @@ namespace {
 #ifndef FL_MT4_STAGES
 #define FL_MT4_STAGES 2
 #endif
-constexpr int BN = 128;            // weight rows per workgroup (= one 128-row scale block)
-constexpr int BK = 128;            // k block (bytes per row per stage)
-constexpr int kWBytes = BN * BK;   // 16 KiB
-constexpr int kUnit = 0x7F;
-
-enum Mode { kOffset = 0, kContiguous = 1, kMasked = 2, kDense = 3 };
-
-struct GemmParams {
-  int mode, E, M, N, K;
-  int n_tiles, m_tiles_upper;
-  long long as_stride_m, as_stride_k, as_stride_g;   // element strides of As (g: masked mode only)
-  long long rows_per_group;             // masked mode: padded rows per group
-  uint16_t* out;
-};
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-__device__ __forceinline__ v8i mk8(uint4 a, uint4 b) {
-  v8i r;
-  r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
-  return r;
-}
-
 template <int MT>
 struct Smem {
   // ring depth: every tile shape runs 2 workgroups per CU (3 stages for the small token tiles, 2 for the 128-token tile)
@@ -151,35 +129,7 @@ __global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void g
   int e = 0;
   long long row0 = 0;     // first row of the tile in A / out
   long long row_end = 0;  // one past the last valid row
-  if (p.mode == kOffset) {
-    int t = mt, found = 0;
-    for (int g = 0; g < p.E; ++g) {
-      const int lo = gmeta[g], hi = gmeta[g + 1];
-      const int tiles = (hi - lo + BM - 1) / BM;
-      if (t < tiles) { e = g; row0 = lo + (long long)t * BM; row_end = hi; found = 1; break; }
-      t -= tiles;
-    }
-    if (!found) return;
-  } else if (p.mode == kContiguous) {
-    row0 = (long long)mt * BM;
-    if (row0 >= p.M) return;
-    e = gmeta[row0];
-    if (e < 0 || e >= p.E) return;
-    row_end = row0 + BM < p.M ? row0 + BM : p.M;
-  } else if (p.mode == kMasked) {
-    const int tpg = (int)((p.rows_per_group + BM - 1) / BM);
-    e = mt / tpg;
-    if (e >= p.E) return;
-    const int mm = gmeta[e];
-    const long long r = (long long)(mt % tpg) * BM;
-    if (r >= mm) return;
-    row0 = (long long)e * p.rows_per_group + r;
-    row_end = (long long)e * p.rows_per_group + mm;
-  } else {
-    row0 = (long long)mt * BM;
-    if (row0 >= p.M) return;
-    row_end = p.M;
-  }
+  if (!locate_tile<BM>(p, gmeta, mt, e, row0, row_end)) return;
   const int n0 = nt * BN;
   const int KB = p.K / BK;
 
@@ -312,6 +262,13 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
   if (a->mode == kDense) avg = a->M;
   int mt = avg <= 32 ? 1 : (avg <= 64 ? 2 : 4);
   if (a->mode == kContiguous) mt = 4;   // groups are 128-row aligned by contract (deep_ep_executor.py:282,290)
+  // many rows per group (prefill regime): 256 x 256 tiles, one 8-wave workgroup per CU (grouped_gemm_fp8_big.hip)
+  static const bool big_on = [] {
+    const char* e = getenv("FLUENT_GEMM_BIG");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  if (big_on && avg >= 192 && a->K >= 2 * BK && a->mode != kContiguous)   // (contiguous groups are only 128-row aligned)
+    return fl_gemm_launch_big(p, a->A, a->As, a->W, a->Ws, a->group_meta, (hipStream_t)stream);
   const int bm = 32 * mt;
   long long m_tiles;
   if (a->mode == kOffset) m_tiles = (a->M + bm - 1) / bm + a->num_groups;

@@ -266,3 +266,25 @@ def test_masked_big_tile_vs_oracle():
         if mm:
             assert rel_mae(om[gi, :mm].cpu(), refm[gi, :mm]) < 1e-3
         assert bool((om[gi, mm:] == 3.0).all())
+
+
+def test_big_tile_contiguous_and_dense_vs_oracle():
+    """>= 192 rows per group on average: the 256 x 256 tile kernel (grouped_gemm_fp8_big.hip) in contiguous mode (128-row
+    aligned groups, a group boundary INSIDE a 256-row tile span) and as the dense GEMM (M not a multiple of 256)."""
+    import deep_gemm
+
+    counts = [384, 128, 640, 256]
+    N, K = 640, 768
+    xq, xs, W, Ws, ex = make_group_case(counts, N, K, seed=21)
+    M = xq.shape[0]
+    m_indices = torch.repeat_interleave(torch.arange(len(counts)), torch.tensor(counts)).to(torch.int32)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous((xq.to(DEV), xs.to(DEV)), (W.to(DEV), Ws.to(DEV)), out, m_indices.to(DEV), True)
+    ref = gemm_ref.grouped_gemm_contiguous(xq, xs, W, Ws, m_indices)
+    assert rel_mae(out.cpu(), ref) < 1e-3
+    # dense: one group
+    xq1, xs1, W1, Ws1, _ = make_group_case([777], 1000, 512, seed=22)
+    out1 = torch.zeros(777, 1000, dtype=torch.bfloat16, device=DEV)
+    deep_gemm.gemm_fp8_fp8_bf16_nt((xq1.to(DEV), xs1.to(DEV)), (W1[0].to(DEV), Ws1[0].to(DEV)), out1, True)
+    ref1 = gemm_ref.grouped_gemm_offset(xq1, xs1, W1, Ws1, torch.tensor([0, 777], dtype=torch.int32))
+    assert rel_mae(out1.cpu(), ref1) < 1e-3
