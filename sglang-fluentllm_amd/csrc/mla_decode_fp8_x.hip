@@ -584,12 +584,16 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
   const int lane = lc0.lane, li = lc0.li, lh = lc0.lh;
 
   // ---- workgroup -> (part, row group) ----
-  const int rgrp = blockIdx.x % p.row_groups;
-#ifdef FL_X_SWAP
-  const int part = (blockIdx.x / p.row_groups) ^ 1;
-#else
-  const int part = blockIdx.x / p.row_groups;
-#endif
+  // The row groups of one part read the same KV pages: they are placed on the SAME XCD (consecutive workgroup ids go
+  // round-robin over the 8 XCDs, each with its own L2), so that the pages come from HBM once per part, not once per
+  // row group (s_q = 4 verify at H = 128: 4 row groups).
+  int rgrp = blockIdx.x % p.row_groups;
+  int part = blockIdx.x / p.row_groups;
+  if (p.row_groups > 1 && p.num_parts % 8 == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    part = (slot / p.row_groups) * 8 + xcd;
+    rgrp = slot % p.row_groups;
+  }
   const int32_t* meta = g_meta + part * FL_MLA_META_W;
   int req = meta[0];
   int tile_b = meta[1];

@@ -271,6 +271,135 @@ def test_graph_capture_replay(fm):
     assert torch.equal(o.cpu().view(torch.int16), o_ref.view(torch.int16))
 
 
+@pytest.mark.parametrize("H", [16, 128])
+def test_mtp_verify_and_draft_steps_in_one_graph(fm, H):
+    """BASELINE config 5 in miniature: one speculative-decode step — verify (s_q = 4 draft tokens, causal inside the
+    block, cache_seqlens = seq_lens + 4: flashmla_backend.py:105-176) followed by 3 draft decode steps whose backends
+    see seq_lens + (i + 1) more tokens (FlashMLAMultiStepDecodeBackend, :411-477) — captured ONCE in a hipGraph over
+    persistent buffers and replayed for two different batches, like CudaGraphRunner.replay (cuda_graph_runner.py:460-525):
+    the batch is padded to the captured size with requests of seq_len fill value 1 whose block-table row points at
+    padding page 0; the scheduler metadata of every backend is recomputed OUTSIDE the graph and copied into the captured
+    buffers (flashmla_backend.py:366-405).  K5 (store the new tokens' KV) and K4 (quantise q) run inside the graph."""
+    from oracle import mla_ref as R
+
+    DRAFT, STEPS, BS_CAP = 4, 3, 4
+    dv = dev()
+
+    def batch(lens, seed):
+        c = make_paged_case([L + DRAFT + STEPS for L in lens], H, seed=seed)      # pages for every token the step adds
+        g = torch.Generator().manual_seed(seed + 1)
+        nb = len(lens)
+        c["q_verify"] = torch.randn(nb, DRAFT, H, 576, generator=g).to(torch.bfloat16)
+        c["q_draft"] = [torch.randn(nb, 1, H, 576, generator=g).to(torch.bfloat16) for _ in range(STEPS)]
+        c["k_verify"] = torch.randn(nb * DRAFT, 1, 576, generator=g).to(torch.bfloat16)
+        c["k_draft"] = [torch.randn(nb, 1, 576, generator=g).to(torch.bfloat16) for _ in range(STEPS)]
+        c["lens"] = lens
+        return c
+
+    cases = [batch([300, 1000, 77], 31), batch([64, 5], 32)]
+    pool_pages = max(c["total_pages"] for c in cases)
+    max_pages = max(c["block_table"].shape[1] for c in cases)
+    slots = pool_pages * 64
+    # ---- persistent graph buffers (flashmla_backend.py:289-322; kv indices filled with 1, seq_len fill value 1) ----
+    k_lora = torch.zeros(slots, 1, 512, dtype=torch.uint8, device=dv)
+    k_scale = torch.ones(slots, 1, 1, dtype=torch.float32, device=dv)
+    k_rope = torch.zeros(slots, 1, 64, dtype=torch.bfloat16, device=dv)
+    bt = torch.ones(BS_CAP, max_pages, dtype=torch.int32, device=dv)
+    seq_v = torch.ones(BS_CAP, dtype=torch.int32, device=dv)
+    seq_d = [torch.ones(BS_CAP, dtype=torch.int32, device=dv) for _ in range(STEPS)]
+    qv = torch.zeros(BS_CAP, DRAFT, H, 576, dtype=torch.bfloat16, device=dv)
+    qd = [torch.zeros(BS_CAP, 1, H, 576, dtype=torch.bfloat16, device=dv) for _ in range(STEPS)]
+    kv_new = torch.zeros(BS_CAP * DRAFT, 1, 576, dtype=torch.bfloat16, device=dv)
+    kd_new = [torch.zeros(BS_CAP, 1, 576, dtype=torch.bfloat16, device=dv) for _ in range(STEPS)]
+    loc_v = torch.zeros(BS_CAP * DRAFT, dtype=torch.int32, device=dv)           # padded tokens write padding page 0
+    loc_d = [torch.zeros(BS_CAP, dtype=torch.int32, device=dv) for _ in range(STEPS)]
+    meta_v, ns_v = fm.get_mla_metadata(seq_v, DRAFT * H, 1)
+    meta_d, ns_d = zip(*[fm.get_mla_metadata(seq_d[i], H, 1) for i in range(STEPS)])
+    views = dict(k_cache_lora=k_lora.view(pool_pages, 64, 1, 512), k_cache_rope=k_rope.view(pool_pages, 64, 1, 64),
+                 k_scale=k_scale.view(pool_pages, 64, 1, 1))
+
+    def step():
+        outs = []
+        fm.quantize_and_cache_k(kv_new, k_lora, k_scale, k_rope, loc_v, 512)
+        qn, qs, qr = fm.quantize_ckv_per_token_head(qv, 512)
+        outs.append(fm.flash_mla_ckv_fp8_per_token(q_nope=qn, q_rope=qr, q_scale=qs, block_table=bt, cache_seqlens=seq_v,
+                                                   head_dim_v=512, tile_scheduler_metadata=meta_v, num_splits=ns_v,
+                                                   softmax_scale=SCALE, causal=True, **views)[0])
+        for i in range(STEPS):
+            fm.quantize_and_cache_k(kd_new[i], k_lora, k_scale, k_rope, loc_d[i], 512)
+            qn, qs, qr = fm.quantize_ckv_per_token_head(qd[i], 512)
+            outs.append(fm.flash_mla_ckv_fp8_per_token(q_nope=qn, q_rope=qr, q_scale=qs, block_table=bt,
+                                                       cache_seqlens=seq_d[i], head_dim_v=512,
+                                                       tile_scheduler_metadata=meta_d[i], num_splits=ns_d[i],
+                                                       softmax_scale=SCALE, causal=True, **views)[0])
+        return outs
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = step()
+
+    for c in cases:
+        lens, nb = c["lens"], len(c["lens"])
+        P = c["total_pages"] * 64
+        # ---- "replay": copy the batch into the persistent buffers, re-plan every backend, replay ----
+        k_lora[:P].copy_(c["k_lora"]); k_scale[:P].copy_(c["k_scale"]); k_rope[:P].copy_(c["k_rope"])
+        bt.zero_(); bt[:nb, :c["block_table"].shape[1]].copy_(c["block_table"])     # padded rows -> page 0
+        L = torch.tensor(lens, dtype=torch.int32)
+        seq_v.fill_(1); seq_v[:nb].copy_(L + DRAFT)
+        for i in range(STEPS):
+            seq_d[i].fill_(1); seq_d[i][:nb].copy_(L + DRAFT + i + 1)
+        cpu_bt = c["block_table"]
+        def loc_of(b, t):
+            return int(cpu_bt[b, t // 64]) * 64 + t % 64
+        lv = torch.zeros(BS_CAP * DRAFT, dtype=torch.int32)
+        for b in range(nb):
+            for j in range(DRAFT):
+                lv[b * DRAFT + j] = loc_of(b, lens[b] + j)
+        loc_v.copy_(lv)
+        kv_new.zero_(); kv_new[:nb * DRAFT].copy_(c["k_verify"])
+        qv.zero_(); qv[:nb].copy_(c["q_verify"])
+        lds = []
+        for i in range(STEPS):
+            ld = torch.zeros(BS_CAP, dtype=torch.int32)
+            for b in range(nb):
+                ld[b] = loc_of(b, lens[b] + DRAFT + i)
+            lds.append(ld)
+            loc_d[i].copy_(ld)
+            kd_new[i].zero_(); kd_new[i][:nb].copy_(c["k_draft"][i])
+            qd[i].zero_(); qd[i][:nb].copy_(c["q_draft"][i])
+        m, n_ = fm.get_mla_metadata(seq_v, DRAFT * H, 1)
+        meta_v.copy_(m); ns_v.copy_(n_)
+        for i in range(STEPS):
+            m, n_ = fm.get_mla_metadata(seq_d[i], H, 1)
+            meta_d[i].copy_(m); ns_d[i].copy_(n_)
+        graph.replay()
+        torch.cuda.synchronize()
+        # ---- oracle: the same stores and attentions on the CPU copy of the cache ----
+        kl, ks, kr = c["k_lora"].clone(), c["k_scale"].clone(), c["k_rope"].clone()
+        pages = c["total_pages"]
+        def attend(q, seqlens):
+            qn, qs, qr = R.quantize_ckv_per_token_head(q, 512)
+            return R.mla_decode_fp8_per_token(qn, qs, qr, kl.view(pages, 64, 1, 512), ks.view(pages, 64, 1, 1),
+                                              kr.view(pages, 64, 1, 64), cpu_bt, seqlens, SCALE, True)[0]
+        R.quantize_and_cache_k(c["k_verify"], kl, ks, kr, lv[:nb * DRAFT])
+        refs = [attend(c["q_verify"], L + DRAFT)]
+        for i in range(STEPS):
+            R.quantize_and_cache_k(c["k_draft"][i], kl, ks, kr, lds[i][:nb])
+            refs.append(attend(c["q_draft"][i], L + DRAFT + i + 1))
+        for i, (o, ref) in enumerate(zip(outs, refs)):
+            got = o[:nb].cpu().reshape(ref.shape).double()
+            assert torch.isfinite(o.float()).all(), i                       # padded requests included
+            rel = float((got - ref).abs().mean() / ref.abs().mean())
+            assert rel < 3e-2, (H, i, rel)
+        # the stores inside the graph produced the oracle's bytes (padded tokens wrote only into padding page 0)
+        assert torch.equal(k_lora[64:P].cpu(), kl[64:]) and torch.equal(k_rope[64:P].cpu().view(torch.int16), kr[64:].view(torch.int16))
+
+
 # ---------------------------------------------------------------- K2: single fp8 [.,576] cache, scalar descales
 def make_fp8_576_case(lens, H, s_q, seed):
     g = torch.Generator().manual_seed(seed)
