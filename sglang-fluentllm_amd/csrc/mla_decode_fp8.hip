@@ -383,19 +383,61 @@ __device__ __forceinline__ void tile_body(
 
 // Read-only inputs are separate `const __restrict__` kernel arguments so that hipcc proves them invariant: wave-
 // uniform reads (page ids, lengths, scheduler rows) become s_load (lgkmcnt), never vector loads on the vmcnt queue.
+// One page for a LOADER wave (NRG = 1): the barrier protocol of tile_body's section C, then the refill it certifies.
 template <int NRG, int FMT>
-__global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
+__device__ __forceinline__ void loader_page(const LaneConst& lc, const int wave, uint8_t* __restrict__ dma_nope,
+                                            uint8_t* __restrict__ dma_rope, float* __restrict__ dma_scale,
+                                            const uint8_t* __restrict__ src_nope, const uint16_t* __restrict__ src_rope,
+                                            const float* __restrict__ src_scale, const bool more_in_flight) {
+  constexpr int NW = 2 * NRG;
+  constexpr int kNopePerWave = kDmaNopePerTile / NW;
+  constexpr int kRopePerWave = (FMT == 0 ? 8 : 4) / NW;
+  if (more_in_flight) {
+    if constexpr (NRG == 2)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (src_rope != nullptr) {
+#pragma unroll
+    for (int k = 0; k < kRopePerWave; ++k)
+      fl_dma_lds((gbl_ptr_t)(reinterpret_cast<const uint8_t*>(src_rope) + lc.dr[k]),
+                 (lds_ptr_t)(dma_rope + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
+    if constexpr (FMT == 0) fl_dma_lds((gbl_ptr_t)(src_scale + lc.lane), (lds_ptr_t)dma_scale, 4, 0, 0);
+  }
+  if (src_nope != nullptr) {
+#pragma unroll
+    for (int k = 0; k < kNopePerWave; ++k)
+      fl_dma_lds((gbl_ptr_t)(src_nope + lc.dn[k]), (lds_ptr_t)(dma_nope + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
+  }
+}
+
+// NRG = 1 (at most 32 query rows, e.g. the TP8 shard H = 16): two LOADER waves join the two compute waves (the CU's
+// other two SIMDs are idle otherwise).  They only issue the LDS-DMA refills (21 pieces per page and wave, 60-185 issue
+// cycles each — in the compute waves that was most of the PV stage) and keep the barrier protocol.
+constexpr int loader_waves(const int nrg) { return nrg == 1 ? 2 : 0; }
+
+template <int NRG, int FMT>
+__global__ __launch_bounds__(64 * (2 * NRG + loader_waves(NRG)), 1) void mla_decode_fp8_kernel(
     const Params p, const int32_t* __restrict__ g_block_table, const int32_t* __restrict__ g_seqlens,
     const int32_t* __restrict__ g_meta, const int32_t* __restrict__ g_num_splits,
     const uint8_t* __restrict__ g_k_nope, const uint16_t* __restrict__ g_k_rope, const float* __restrict__ g_k_scale,
     const uint8_t* __restrict__ g_q_nope, const uint16_t* __restrict__ g_q_rope, const float* __restrict__ g_q_scale) {
   constexpr int NW = 2 * NRG;
+  constexpr int LD = loader_waves(NRG);
+  static_assert(LD == 0 || LD == NW, "the loaders take over the compute waves' piece mapping one to one");
   constexpr int kTokBytes = FMT == 0 ? kDN : kDN + kDR;    // bytes per token row of the latent tensor in HBM
   constexpr int kRopeTok = FMT == 0 ? kDR * 2 : kDR;        // bytes per token of rope (bf16 / fp8)
   __shared__ __attribute__((aligned(16))) uint8_t smem[kLdsBytes];
 
   const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_loader = LD > 0 && wave_id >= NW;
+  const bool issues_dma = LD == 0 || is_loader;
+  const int wave = is_loader ? wave_id - NW : wave_id;   // compute wave index, or DMA piece owner index
   const int rg = wave % NRG;   // row group inside the workgroup
   const int W = wave / NRG;    // token half (QK) / d half (PV)
   LaneConst lc;
@@ -493,6 +535,79 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
   const unsigned long long tstart = tlast;
 #endif
 
+  if (is_loader) {
+    // ---- loader waves: the request loop of the compute waves reduced to its barriers and its LDS-DMA ----
+    for (; req < p.bs; ++req, tile_b = 0) {
+      if (req > end_req || (req == end_req && end_tile == 0)) break;
+      const int L = g_seqlens[req];
+      const int nt = L > 0 ? (L + kPage - 1) / kPage : 0;
+      int tile_e = req < end_req ? nt : (end_tile < nt ? end_tile : nt);
+      if (tile_e < tile_b) tile_e = tile_b;
+      const int n = tile_e - tile_b;
+      int win_base = 0;
+      int pg_vec = 0;
+      auto load_window = [&](int base) {
+        win_base = base;
+        const int t = base + lane;
+        int pg = 0;
+        if (t < n) pg = g_block_table[(long long)req * p.bt_stride + tile_b + t];
+        pg_vec = (pg < 0 || pg >= p.num_pages) ? 0 : pg;
+      };
+      load_window(0);
+      auto page_of = [&](int t) { return (long long)__builtin_amdgcn_readlane(pg_vec, t - win_base); };
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      auto rope_src = [&](int t) {
+        const long long pg = page_of(t);
+        return FMT == 0 ? g_k_rope + pg * (kPage * kDR) : reinterpret_cast<const uint16_t*>(g_k_nope + pg * (kPage * kTokBytes));
+      };
+      auto scale_src = [&](int t) { return FMT == 0 ? g_k_scale + page_of(t) * kPage : g_k_scale; };
+      auto nope_src = [&](int t) { return g_k_nope + page_of(t) * (kPage * kTokBytes); };
+      auto ring = [&](int t) { return smem + kOffRing + (t & 3) * kSlotBytes; };
+      auto rope_slot = [&](int t) { return smem + kOffRope + (t & 1) * kRopeBytes; };
+      auto scale_slot = [&](int t) { return reinterpret_cast<float*>(smem + kOffScale + (t & 1) * (kPage * 4)); };
+      // prologue [r0 s0 n0] [r1 s1 n1] [n2]: loader_page without its wait + barrier is exactly one "issue" call
+      auto issue = [&](const uint8_t* sn, uint8_t* dn, const uint16_t* sr, const float* ss, uint8_t* dr, float* ds) {
+        constexpr int kNopePerWave = kDmaNopePerTile / NW;
+        constexpr int kRopePerWave = (FMT == 0 ? 8 : 4) / NW;
+        if (sr != nullptr) {
+#pragma unroll
+          for (int k = 0; k < kRopePerWave; ++k)
+            fl_dma_lds((gbl_ptr_t)(reinterpret_cast<const uint8_t*>(sr) + lc.dr[k]),
+                       (lds_ptr_t)(dr + (wave * kRopePerWave + k) * 1024), 16, 0, 0);
+          if constexpr (FMT == 0) fl_dma_lds((gbl_ptr_t)(ss + lane), (lds_ptr_t)ds, 4, 0, 0);
+        }
+        if (sn != nullptr) {
+#pragma unroll
+          for (int k = 0; k < kNopePerWave; ++k)
+            fl_dma_lds((gbl_ptr_t)(sn + lc.dn[k]), (lds_ptr_t)(dn + (wave * kNopePerWave + k) * 1024), 16, 0, 0);
+        }
+      };
+      if (n > 0) issue(nope_src(0), ring(0), rope_src(0), scale_src(0), rope_slot(0), scale_slot(0));
+      if (n > 1) issue(nope_src(1), ring(1), rope_src(1), scale_src(1), rope_slot(1), scale_slot(1));
+      if (n > 2) issue(nope_src(2), ring(2), nullptr, nullptr, nullptr, nullptr);
+      if (n > 2) {   // leave [r1 s1 n1] [n2] in flight (same counts as the compute waves of NRG = 1 had)
+        if constexpr (FMT == 0) asm volatile("s_waitcnt vmcnt(37)" ::: "memory");   // (4+1+16) + 16
+        else asm volatile("s_waitcnt vmcnt(34)" ::: "memory");                      // (2+0+16) + 16
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      for (int i = 0; i < n; ++i) {
+        if (i + 3 >= win_base + 64 && i + 3 < n) load_window(i);   // pages i .. i+63
+        const uint8_t* sn = i + 3 < n ? nope_src(i + 3) : nullptr;
+        const uint16_t* sr = i + 2 < n ? rope_src(i + 2) : nullptr;
+        const float* ss = i + 2 < n ? scale_src(i + 2) : nullptr;
+        loader_page<NRG, FMT>(lc, wave, ring(i + 3), rope_slot(i), scale_slot(i), sn, sr, ss, i + 2 < n);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
   for (; req < p.bs; ++req, tile_b = 0, split_idx = 0) {
     if (req > end_req || (req == end_req && end_tile == 0)) break;
     const int L = g_seqlens[req];
@@ -513,7 +628,7 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
 #pragma unroll
     for (int s = 0; s < 4; ++s) qr[s] = as_bf8(make_uint4(0, 0, 0, 0));
     if constexpr (FMT == 1) ks_const = p.descale_k ? *p.descale_k : 1.f;
-    if (row_ok) {
+    if (row_ok && !is_loader) {
       const uint8_t* qp = g_q_nope + qrow * kTokBytes + lh * 32;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -596,9 +711,11 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
           fl_dma_lds((gbl_ptr_t)(sn + lc.dn[k]), (lds_ptr_t)(dn + (wave * kNopePerWave + k) * 1024),
                                            16, 0, 0);
       };
-      if (n > 0) { dma_rs(0); dma_n(0); }
-      if (n > 1) { dma_rs(1); dma_n(1); }
-      if (n > 2) dma_n(2);
+      if (issues_dma) {
+        if (n > 0) { dma_rs(0); dma_n(0); }
+        if (n > 1) { dma_rs(1); dma_n(1); }
+        if (n > 2) dma_n(2);
+      }
       if (n > 2) {   // leave [r1 s1 n1] [n2] in flight
         if constexpr (NRG == 2 && FMT == 0) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");        // (2+1+8) + 8
         else if constexpr (NRG == 1 && FMT == 0) asm volatile("s_waitcnt vmcnt(37)" ::: "memory");   // (4+1+16) + 16
@@ -611,7 +728,7 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
     }
     // page 0: scale triples + first half of the QK operands (later pages get them in the previous page's PV shadow)
     QkPrefetch pre;
-    if (n > 0) {
+    if (n > 0 && !is_loader) {
       scale_prep<FMT>(reinterpret_cast<const float*>(smem + kOffScale), scratch, ks_const, W, li, lh, tile_b * kPage, L);
       qk_prefetch<FMT>(pre, lc, smem + kOffRing, smem + kOffRope, W);
     }
@@ -632,6 +749,7 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
           ss = reinterpret_cast<const float*>(sr);   // unused (non-null)
         }
       }
+      if (LD > 0) { sn = nullptr; sr = nullptr; ss = nullptr; }   // the loader waves issue the refill
       tile_body<NRG, FMT>(st, pre, lc, qn, qr, qr8, qs, ks_const, W, rg, wave,
                      smem + kOffRing + ((i + 1) & 3) * kSlotBytes, smem + kOffRope + ((i + 1) & 1) * kRopeBytes,
                      reinterpret_cast<const float*>(smem + kOffScale + ((i + 1) & 1) * (kPage * 4)), i + 1 < n,
@@ -654,7 +772,7 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // everyone is past the last page (P buffers free)
     float* lm = reinterpret_cast<float*>(smem + kOffPbuf);   // [rg][W][3][32]
-    if (lh == 0) {
+    if (lh == 0 && !is_loader) {
       lm[((rg * 2 + W) * 3 + 0) * 32 + li] = l_tot;
       lm[((rg * 2 + W) * 3 + 1) * 32 + li] = lq_tot;
       lm[((rg * 2 + W) * 3 + 2) * 32 + li] = st.m_w;
@@ -670,7 +788,7 @@ __global__ __launch_bounds__(128 * NRG, 1) void mla_decode_fp8_kernel(
     // split-KV partials are normalised by lq, so they must also be COMBINED with lq-based weights (then the combine is
     // exactly the unsplit sum O/lq); the exact LSE travels next to it for the reported lse.
     const float lseq_nat = lq > 0.f ? (__builtin_amdgcn_logf(lq) + st.m_o - kPShift) * 0.6931471805599453f : -INFINITY;
-    if (row_ok) {
+    if (row_ok && !is_loader) {
       const int slot_idx = split_base + split_idx;
       if (lh == 0 && W == 0) {
         if (is_split) {
@@ -776,7 +894,7 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   }
   const int nrg = p.rows > 32 ? 2 : 1;
   p.row_groups = (p.rows + 32 * nrg - 1) / (32 * nrg);
-  const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(128 * nrg);
+  const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(64 * (2 * nrg + loader_waves(nrg)));
 #define FL_LAUNCH(NRG_, FMT_)                                                                                          \
   mla_decode_fp8_kernel<NRG_, FMT_><<<grid, block, 0, stream>>>(                                                       \
       p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, a->num_splits, (const uint8_t*)a->k_nope,        \
