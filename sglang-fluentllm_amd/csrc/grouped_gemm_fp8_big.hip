@@ -174,8 +174,10 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big_kernel(const Gemm
     for (int t = 0; t < 8; ++t) {
       const int j = t >> 1, i = t & 1;
 #ifndef FL_GEMM_NOCOMPUTE   // experiment switch: operand streaming only (results are garbage)
-      mfma_first(part[t & 1], wa[i][0], b0);
+      __builtin_amdgcn_s_setprio(1);   // the two waves of a SIMD are at different phases: the one with MFMAs to issue goes
+      mfma_first(part[t & 1], wa[i][0], b0);   // first (+2.7 % / +1.5 % on w13 / w2 at T=16384)
       mfma_acc(part[t & 1], wa[i][1], b1);
+      __builtin_amdgcn_s_setprio(0);
 #else
 #pragma unroll
       for (int r = 0; r < 16; ++r) part[t & 1][r] = (float)(wa[i][0][0] + b0[1] + wa[i][1][2] + b1[3]);
