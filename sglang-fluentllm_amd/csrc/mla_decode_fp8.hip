@@ -36,6 +36,7 @@
 //
 // Algorithmic bytes per (request, layer call): seq*644 (KV) + s_q*h_q*(644 + 1024) (Q in, O out) + 4*ceil(seq/64).
 #include "mla_decode_shared.h"
+#include <cstdlib>
 
 using namespace fl_mla;
 
@@ -884,14 +885,20 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   p.num_pages = a->num_pages; p.bt_stride = a->block_table_stride;
   p.out = (uint16_t*)a->out; p.lse = a->lse; p.o_accum = a->o_accum; p.lse_accum = a->lse_accum;
   p.partial_bf16 = 0;
-  // rows > 64 (e.g. TP1, H=128): 128-row workgroups that ingest every KV byte once (mla_decode_fp8_x.hip; FLUENT_MLA_X=0
-  // keeps the 64-row mapping).
-  // rows <= 32 (e.g. the TP8 shard, H=16): one row group per workgroup (2 waves); otherwise 2 row groups (4 waves).
+  // The slot-pipelined mapping (mla_decode_fp8_x.hip): 128-row workgroups for rows > 64 (e.g. TP1, H=128); for 33..64 rows
+  // two compute waves + two loader waves (measured H=64: 102.5 vs 114 us; FLUENT_MLA_X_SMALL=0 keeps this file's kernel).
+  // At most 32 rows stay here: ONE slot-pipelined compute wave would carry all 40 MFMAs of a page on one SIMD (H=16:
+  // 85.8 us) where this file's two half-waves + two loaders take 78.3.  FLUENT_MLA_X=0: this file for every shape.
   // fl_mla_num_parts sizes the scheduler's part count with the same rule.
-  if (fl_mla_use_x() && p.rows > 64) {
-    p.row_groups = (p.rows + 127) / 128;
+  static const bool x_small = [] {
+    const char* e = getenv("FLUENT_MLA_X_SMALL");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  if (fl_mla_use_x() && (p.rows > 64 || (x_small && p.rows > 32))) {
+    p.row_groups = (p.rows + 127) / 128;   // (recomputed by the callee from the rows)
     return fl_mla_decode_fp8_x_impl(a, p, stream);
   }
+  // rows <= 32 (e.g. the TP8 shard, H=16): one row group per workgroup (2 waves + 2 loaders); otherwise 2 row groups.
   const int nrg = p.rows > 32 ? 2 : 1;
   p.row_groups = (p.rows + 32 * nrg - 1) / (32 * nrg);
   const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(64 * (2 * nrg + loader_waves(nrg)));

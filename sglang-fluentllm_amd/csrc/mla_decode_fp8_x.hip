@@ -353,7 +353,7 @@ __device__ __forceinline__ unsigned dn_off(const LaneConst& lc, const int k) {
 // so the VALU / transcendental work of a block always sits in the shadow of independent MFMAs.  All LDS regions are
 // distinct __restrict__ parameters of ONE inlined function (see mla_decode_fp8.hip: otherwise hipcc drains the LDS-DMA
 // queue with vmcnt(0) before every ds_read).
-template <int FMT, bool has_cur, bool has_prev, bool FAST>
+template <int FMT, bool has_cur, bool has_prev, bool FAST, bool SELF_DMA>
 __device__ __forceinline__ void page_step(
     ReqState& st, LaneConst& lc_io, const v8i (&qn)[8], const v8bf (&qr)[4], const v8i qr8, const float qs,
     const float ks_const, const int wave,
@@ -388,8 +388,10 @@ __device__ __forceinline__ void page_step(
 
   // ---- page i landed for every wave (issue order per step: rope, scale, latent of ONE page); every wave is done with
   //      page i-2, whose slots are refilled below ----
+  // (SELF_DMA = false: loader waves issue and wait for the LDS-DMA, mla_decode_x_kernel; the barrier carries their wait)
 #ifndef FL_X_NOWAIT   // experiment switch: timing without the page-landed wait (results are garbage)
-  if (next_in_flight) {
+  if (!SELF_DMA) {
+  } else if (next_in_flight) {
     if constexpr (FMT == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");   // page i+1: 2 rope + 1 scale + 8 latent
     else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   } else {
@@ -402,7 +404,7 @@ __device__ __forceinline__ void page_step(
   // The LDS-DMA refill (page i+2: 2 rope + 1 scale + 8 latent pieces per wave, in this order — the counted waits rely
   // on it) and the scale triples of page i are spread over the 12 MFMA slots of QK block 0: issued in one burst at the
   // top of the step they cost 100-185 cycles per piece (measured: 820 + most of a 2700-cycle QK stage).
-  const bool do_dma = FAST ? true : (src_nope != nullptr);
+  const bool do_dma = SELF_DMA && (FAST ? true : (src_nope != nullptr));
   auto dma_piece = [&](const int k) {   // k = 0 .. kRopePerWave + (FMT == 0) + kNopePerWave - 1
     if (k < kRopePerWave) {
       dma_x4(src_rope, lc.dr[k < kRopePerWave ? k : 0], dma_rope + (wave * kRopePerWave + k) * 1024);
@@ -535,19 +537,30 @@ __device__ __forceinline__ void page_step(
   FL_T(4);   // PV
 }
 
-template <int FMT>
-__global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
+// NWC compute waves of 32 query rows each.  NWC = 4: every wave also issues its share of the LDS-DMA inside its MFMA
+// slots.  NWC = 2 (33..64 query rows per request, e.g. MTP draft steps at H = 64; a single compute wave — NWC = 1 —
+// is slower than the two half-waves of mla_decode_fp8.hip):
+// the CU's remaining SIMDs run two LOADER waves that issue every refill and keep the barrier protocol — an LDS-DMA piece
+// costs 60-185 issue cycles, ~1100 of a compute wave's ~4400 cycles per page.
+template <int FMT, int NWC>
+__global__ __launch_bounds__(64 * (NWC + (NWC == 4 ? 0 : 2)), 1) void mla_decode_x_kernel(
     const Params p, const int32_t* __restrict__ g_block_table, const int32_t* __restrict__ g_seqlens,
     const int32_t* __restrict__ g_meta, const int32_t* __restrict__ g_num_splits,
     const uint8_t* __restrict__ g_k_nope, const uint16_t* __restrict__ g_k_rope, const float* __restrict__ g_k_scale,
     const uint8_t* __restrict__ g_q_nope, const uint16_t* __restrict__ g_q_rope, const float* __restrict__ g_q_scale) {
   constexpr int kTokBytes = FMT == 0 ? kDN : kDN + kDR;    // bytes per token row of the latent tensor in HBM
   constexpr int kRopeTok = FMT == 0 ? kDR * 2 : kDR;        // bytes per token of rope (bf16 / fp8)
-  constexpr int kRopePerWave = (FMT == 0 ? 8 : 4) / kNW;
+  constexpr bool SELF_DMA = NWC == 4;
+  constexpr int kDW = SELF_DMA ? 4 : 2;                       // waves that issue LDS-DMA
+  constexpr int kNopePW = kDmaNopePerTile / kDW;              // latent pieces per DMA wave per page (8 / 16)
+  constexpr int kRopePerWave = (FMT == 0 ? 8 : 4) / kDW;      // rope pieces per DMA wave per page
+  static_assert(SELF_DMA || kRopePerWave <= 4, "loader rope pieces");
   __shared__ __attribute__((aligned(16))) uint8_t smem[kLdsBytes];
 
   const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_loader = !SELF_DMA && wave_id >= NWC;
+  const int wave = is_loader ? wave_id - NWC : wave_id;       // compute wave index, or DMA wave index of a loader
   LaneConst lc0;
   lc0.lane = tid & 63;
   lc0.li = lc0.lane & 31;
@@ -571,7 +584,7 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     lc.dn_row = (unsigned)((wave * kNopePerWave * 2 + lh) * kTokBytes);
     lc.dn_x = (unsigned)((li ^ lh) << 4);
 #pragma unroll
-    for (int k = 0; k < kRopePerWave; ++k) {   // BYTE offsets inside the page's rope block
+    for (int k = 0; k < (SELF_DMA ? kRopePerWave : 0); ++k) {   // BYTE offsets inside the page's rope block
       if constexpr (FMT == 0) {
         const int T = (wave * kRopePerWave + k) * 8 + (lane >> 3);   // 8 token rows of 128 B per piece
         lc.dr[k] = (unsigned)(T * 128 + (((lane & 7) ^ ((T >> 1) & 7)) << 4));
@@ -607,7 +620,96 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
   unsigned long long tvar = tlast;
   const unsigned long long tstart = tlast;
 #endif
-  const int row = rgrp * (32 * kNW) + wave * 32 + li;   // query row of this lane
+  if (is_loader) {
+    // ---- loader waves (NWC < 4): the request loop of the compute waves reduced to its barriers and its LDS-DMA.  Piece
+    //      mapping as in the compute waves of NWC = 4, with 16 latent + 4 (2) rope + 1 scale pieces per loader and page;
+    //      issue order per page: rope, scale, latent (the counted waits rely on it). ----
+    const unsigned ldn_row = (unsigned)((wave * kNopePW * 2 + lh) * kTokBytes);
+    const unsigned ldn_x = (unsigned)((li ^ lh) << 4);
+    unsigned ldr[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < kRopePerWave; ++k) {
+      if constexpr (FMT == 0) {
+        const int T = (wave * kRopePerWave + k) * 8 + (lane >> 3);
+        ldr[k] = (unsigned)(T * 128 + (((lane & 7) ^ ((T >> 1) & 7)) << 4));
+      } else {
+        const int T = (wave * kRopePerWave + k) * 16 + (lane >> 2);
+        ldr[k] = (unsigned)(T * kTokBytes + kDN + (((lane & 3) ^ ((T >> 2) & 3)) << 4));
+      }
+    }
+    constexpr int kPiecesL = kRopePerWave + (FMT == 0 ? 1 : 0) + kNopePW;   // 21 / 18
+    static_assert(SELF_DMA || kPiecesL == (FMT == 0 ? 21 : 18), "vmcnt immediates below");
+    for (; req < p.bs; ++req, tile_b = 0) {
+      if (req > end_req || (req == end_req && end_tile == 0)) break;
+      const int L = g_seqlens[req];
+      const int nt = L > 0 ? (L + kPage - 1) / kPage : 0;
+      int tile_e = req < end_req ? nt : (end_tile < nt ? end_tile : nt);
+      if (tile_e < tile_b) tile_e = tile_b;
+      const int n = tile_e - tile_b;
+      int win_base = 0;
+      int pg_vec = 0;
+      auto load_window = [&](int base) {
+        win_base = base;
+        const int t = base + lane;
+        int pg = 0;
+        if (t < n) pg = g_block_table[(long long)req * p.bt_stride + tile_b + t];
+        pg_vec = (pg < 0 || pg >= p.num_pages) ? 0 : pg;
+      };
+      auto page_of = [&](int t) { return (long long)__builtin_amdgcn_readlane(pg_vec, t - win_base); };
+      auto issue_page = [&](const int t) {
+        const long long pg = page_of(t);
+        const uint8_t* sn = g_k_nope + pg * (kPage * kTokBytes);
+        const uint8_t* sr = FMT == 0 ? reinterpret_cast<const uint8_t*>(g_k_rope) + pg * (kPage * kRopeTok) : sn;
+        uint8_t* dr = smem + kOffRope + (t % kRopeSlots) * kRopeBytes;
+#pragma unroll
+        for (int k = 0; k < kRopePerWave; ++k) dma_x4(sr, ldr[k], dr + (wave * kRopePerWave + k) * 1024);
+        if constexpr (FMT == 0)
+          dma_x1(g_k_scale + pg * kPage, (unsigned)lane * 4u,
+                 reinterpret_cast<float*>(smem + kOffScale + (t % kRopeSlots) * (kPage * 4)));
+        uint8_t* dn = smem + kOffRing + (t & 3) * kSlotBytes;
+#pragma unroll
+        for (int k = 0; k < kNopePW; ++k)
+          dma_x4(sn, ldn_row + (unsigned)k * 2u * kTokBytes + (ldn_x ^ (((unsigned)k & 7u) << 5)), dn + (wave * kNopePW + k) * 1024);
+      };
+      load_window(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // request start
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+          load_window(0);
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        if (n > 0) issue_page(0);
+        if (n > 1) issue_page(1);
+        if (n > 0) {
+          for (int i = 0; i <= n; ++i) {   // the n + 1 pipeline steps of the compute waves
+            if (i + 2 >= win_base + 64 && i + 2 < n) load_window(i + 2);
+            if (i > 0 && i + 1 < n) {      // page i has landed, page i + 1 may stay in flight
+              if constexpr (FMT == 0) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (i + 2 < n) issue_page(i + 2);
+          }
+        }
+        if (pass == 1) break;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // redo vote
+        const int* flag = reinterpret_cast<const int*>(smem + kOffFlag);
+        int any_redo = 0;
+#pragma unroll
+        for (int w = 0; w < NWC; ++w) any_redo |= flag[w];
+        if (!any_redo) break;
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();     // epilogue
+    }
+    return;
+  }
+  const int row = rgrp * (32 * NWC) + wave * 32 + li;   // query row of this lane
   const bool row_ok = row < p.rows;
 
   for (; req < p.bs; ++req, tile_b = 0, split_idx = 0) {
@@ -648,7 +750,7 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
     auto rope_slot = [&](int t) { return smem + kOffRope + (t % kRopeSlots) * kRopeBytes; };
     auto scale_slot = [&](int t) { return reinterpret_cast<float*>(smem + kOffScale + (t % kRopeSlots) * (kPage * 4)); };
     auto scr = [&](int t) {
-      return reinterpret_cast<float*>(smem + kOffScratch + ((t & 1) * kNW + wave) * kScratchPerWave);
+      return reinterpret_cast<float*>(smem + kOffScratch + ((t & 1) * NWC + wave) * kScratchPerWave);
     };
     // ---- prologue: pages 0 and 1 (issue order per page: rope, scale, latent — the counted waits rely on it), issued
     //      BEFORE the Q loads and the O initialisation so that their HBM latency overlaps; step 0 waits with vmcnt(0) ----
@@ -665,8 +767,10 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
       for (int k = 0; k < kNopePerWave; ++k)
         dma_x4(sn, dn_off<FMT>(lc, k), ring(t) + (wave * kNopePerWave + k) * 1024);
     };
-    if (n > 0) dma_page(0);
-    if (n > 1) dma_page(1);
+    if constexpr (SELF_DMA) {
+      if (n > 0) dma_page(0);
+      if (n > 1) dma_page(1);
+    }
     FL_T(9);   // prologue: DMA issue of pages 0 and 1
 
     // ---- Q fragments (B operands), once per request ----
@@ -728,8 +832,10 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
       load_window(0);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (n > 0) dma_page(0);
-      if (n > 1) dma_page(1);
+      if constexpr (SELF_DMA) {
+        if (n > 0) dma_page(0);
+        if (n > 1) dma_page(1);
+      }
     }
 
     // ---- n + 1 pipeline steps: step i = QK(i), softmax(i) || PV(i-1) ----
@@ -745,7 +851,7 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
       ss = src_scale_of(i + 2);                                                                                        \
     }                                                                                                                  \
     const int tok0 = (tile_b + i) * kPage;                                                                             \
-    page_step<FMT, HC, HP, FA>(st, lc0, qn, qr, qr8, qs, ks_const, wave, ring(i), rope_slot(i), scale_slot(i), scr(i),     \
+    page_step<FMT, HC, HP, FA, SELF_DMA>(st, lc0, qn, qr, qr8, qs, ks_const, wave, ring(i), rope_slot(i), scale_slot(i), scr(i),     \
                            ring(i + 3), scr(i + 1), ring(i + 2), rope_slot(i + 2), scale_slot(i + 2), sn, sr, ss, tok0, \
                            L, L_row, tok0 + kPage > L_min, tok0 > L_min, i > 0 && i + 1 < n FL_T_ARGS);                \
   }
@@ -774,7 +880,9 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
       if (lane == 0) flag[wave] = vote;
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      const int any_redo = flag[0] | flag[1] | flag[2] | flag[3];
+      int any_redo = 0;
+#pragma unroll
+      for (int w = 0; w < NWC; ++w) any_redo |= flag[w];
       if (!any_redo) break;
       mo_preset = fmaxf(st.mw[0], st.mw[1]);
     }
@@ -818,7 +926,7 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
       asm volatile("" : "+v"(lane));
       const int li = lane & 31, lh = lane >> 5;
       float* stg = reinterpret_cast<float*>(smem + kOffRing) + wave * (32 * kStgStride);
-      const int row0 = rgrp * (32 * kNW) + wave * 32;
+      const int row0 = rgrp * (32 * NWC) + wave * 32;
       const int slot_idx = split_base + split_idx;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -872,18 +980,21 @@ __global__ __launch_bounds__(64 * kNW, 1) void mla_decode_x_kernel(
 
 int fl_mla_decode_fp8_x_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipStream_t stream) {
   Params p = p_in;
-  const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(64 * kNW);
+  // compute waves per workgroup from the query rows per request (fl_mla_num_parts sizes the part count with the same rule)
+  const int nwc = p.rows <= 64 ? 2 : 4;   // (at most 32 rows: mla_decode_fp8.hip, see its dispatcher)
+  p.row_groups = (p.rows + 32 * nwc - 1) / (32 * nwc);
+  const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(64 * (nwc + (nwc == 4 ? 0 : 2)));
   p.partial_bf16 = 1;   // split partials travel as bf16 rows (half the bytes of the f32 layout of mla_decode_fp8.hip)
-  if (a->kv_format == FL_KV_FP8_PER_TOKEN)
-    mla_decode_x_kernel<0><<<grid, block, 0, stream>>>(p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata,
-                                                        a->num_splits, (const uint8_t*)a->k_nope,
-                                                        (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope,
-                                                        (const uint16_t*)a->q_rope, a->q_scale);
-  else
-    mla_decode_x_kernel<1><<<grid, block, 0, stream>>>(p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata,
-                                                        a->num_splits, (const uint8_t*)a->k_nope,
-                                                        (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope,
-                                                        (const uint16_t*)a->q_rope, a->q_scale);
+#define FL_X_LAUNCH(FMT_, NWC_)                                                                                        \
+  mla_decode_x_kernel<FMT_, NWC_><<<grid, block, 0, stream>>>(                                                         \
+      p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, a->num_splits, (const uint8_t*)a->k_nope,       \
+      (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale)
+  if (a->kv_format == FL_KV_FP8_PER_TOKEN) {
+    if (nwc == 4) FL_X_LAUNCH(0, 4); else FL_X_LAUNCH(0, 2);
+  } else {
+    if (nwc == 4) FL_X_LAUNCH(1, 4); else FL_X_LAUNCH(1, 2);
+  }
+#undef FL_X_LAUNCH
   FL_CHECK_LAUNCH("mla_decode_x_kernel");
   // (an in-kernel merge by the last-arriving part was measured: +77 us — one workgroup per request merging row by row is
   //  latency-bound, and the bytes are the same; the combine kernel spreads them over the whole chip)
