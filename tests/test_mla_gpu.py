@@ -169,6 +169,25 @@ def test_decode_rescale_branch_spike(fm):
     check(o, lse, ref, rlse, "spike")
 
 
+@pytest.mark.parametrize("H", [16, 64, 128])
+def test_decode_reference_jump_beyond_block_scale_range(fm, H):
+    """A key late in the sequence beats the first page's maximum by > 69 nats for one query row: the fixed-O-reference
+    mapping (s_q*H > 32) cannot express that jump as an E8M0 block scale and repeats the request with the reference preset
+    (the `redo` vote — with loader waves at H = 64); the 64-row mapping takes its O-rescale branch."""
+    from oracle import mla_ref as R
+
+    c = make_paged_case([1500, 200], H, seed=21)
+    t = 1400                                                 # page 21 of request 0 (second split part at H = 128)
+    slot = int(c["block_table"][0, t // 64]) * 64 + t % 64
+    key = torch.zeros(1, 1, 576)
+    key[0, 0, :512] = c["q"][0, 0, 3, :512].float() * 4.0    # logit ~ 4 |q|^2 / sqrt(192) >> 69 nats above the rest
+    R.quantize_and_cache_k(key.to(torch.bfloat16), c["k_lora"], c["k_scale"], c["k_rope"], torch.tensor([slot], dtype=torch.int32))
+    o, lse, ref, rlse, _ = run_decode(fm, c, H)
+    check(o, lse, ref, rlse, f"jump_H{H}")
+    # the peaked row returns (almost exactly) the planted token's latent
+    assert float((o[0, 0, 3].double() - ref[0, 0, 3]).abs().max()) < 5e-2 * float(ref[0, 0, 3].abs().max())
+
+
 def test_decode_vs_reference_backend_golden(fm):
     """End to end against the REAL reference's TorchNativeAttnBackend output (bf16 KV): quantise the golden cache
     with K5, quantise q with K4, decode with K1.  Tolerance covers per-token FP8 of K and q."""
