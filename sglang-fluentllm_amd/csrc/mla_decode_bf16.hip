@@ -156,8 +156,15 @@ __global__ __launch_bounds__(256, 1) void mla_decode_bf16_kernel(
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  const int rgrp = blockIdx.x % p.row_groups;
-  const int part = blockIdx.x / p.row_groups;
+  // the row groups of one part stream the same KV pages: same XCD (workgroup ids go round-robin over the 8 XCDs, each with
+  // its own L2), so the pages come from HBM once per part instead of once per row group
+  int rgrp = blockIdx.x % p.row_groups;
+  int part = blockIdx.x / p.row_groups;
+  if (p.row_groups > 1 && p.num_parts % 8 == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    part = (slot / p.row_groups) * 8 + xcd;
+    rgrp = slot % p.row_groups;
+  }
   const int32_t* meta = g_meta + part * FL_MLA_META_W;
   int req = meta[0];
   int tile_b = meta[1];
