@@ -13,6 +13,8 @@ wl = bench.build_workload(dev, layers, bs, seq, H, seed=1)
 if os.environ.get("SHARE_PAGES"):   # experiment: every request reads request 0's pages (100 % L2 hits after the first)
     k = int(os.environ["SHARE_PAGES"])
     wl["block_table"] = wl["block_table"][torch.arange(bs, device=dev) // k * k].contiguous()
+if os.environ.get("SEQ_PAGES"):    # experiment: pages in address order instead of randomly permuted (TLB / DRAM locality)
+    wl["block_table"] = (torch.arange(bs * (seq // 64), device=dev, dtype=torch.int32) + 1).view(bs, -1).contiguous()
 meta, ns = fm.get_mla_metadata(wl["seqlens"], H, 1)
 qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
 pages = wl["pages"]
