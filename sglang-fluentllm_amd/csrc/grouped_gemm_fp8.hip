@@ -268,7 +268,11 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
     return !(e != nullptr && e[0] == '0');
   }();
   // (contiguous groups are only 128-row aligned; the big tile addresses a weight panel with 32-bit offsets)
-  if (big_on && avg >= 192 && a->K >= 2 * BK && a->mode != kContiguous && (long long)a->N * a->K < (1ll << 32))
+  static const long long big_min = [] {
+    const char* e = getenv("FLUENT_GEMM_BIG_MIN_ROWS");
+    return e != nullptr ? atoll(e) : 192ll;
+  }();
+  if (big_on && avg >= big_min && a->K >= 2 * BK && a->mode != kContiguous && (long long)a->N * a->K < (1ll << 32))
     return fl_gemm_launch_big(p, a->A, a->As, a->W, a->Ws, a->group_meta, (hipStream_t)stream);
   const int bm = 32 * mt;
   long long m_tiles;

@@ -201,9 +201,9 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big_kernel(const Gemm
       sc_prev = sc_now;
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the last tile: its pair needs 2 x 16 passes after issue
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                 : "+v"(part[1]));
+    // the last tile: a 16-pass XDL write needs 18 wait states (of 4 clocks: probes/probe_snop.hip measures s_nop 7 = 36
+    // clocks) before a VALU read; its pair issued before the last refill piece and the promotion of tile 6 (> 250 clocks)
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(part[1]));
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[1][3][r] = fmaf(part[1][r], sc_prev, acc[1][3][r]);
     asm volatile("" : "+v"(acc[1][3]));

@@ -158,7 +158,8 @@ __device__ __forceinline__ void mfma_fp8(v16f& acc, const v8i a, const v8i b) {
                : "+v"(acc)
                : "v"(a), "v"(b), "v"(kUnitScale));
 }
-#define FL_MFMA_DRAIN() asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory")
+// (a 16-pass XDL write needs 18 wait states of 4 clocks before a VALU read; s_nop 7 = 8 wait states, measured 36 clocks)
+#define FL_MFMA_DRAIN() asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1" ::: "memory")
 
 // Every LDS read of the softmax is issued TWO chunks (MFMA slots) before its first use: the LDS round trip is ~140
 // cycles unloaded, more than one 64-cycle slot.
