@@ -115,6 +115,9 @@ typedef struct FlGemmArgs {
   const float* Ws;            /* f32 [E, ceil(N/128), K/128] */
   void* out;                  /* bf16 [M, N] */
   const int32_t* group_meta;
+  void* workspace;            /* optional scratch (f32 partials) for split-K of problems with few tiles — the dense decode GEMMs of
+                               * the MLA projections: [T<=256, K] x [N, K] has N/128 tiles for 256 CUs; NULL = never split */
+  int64_t workspace_bytes;
 } FlGemmArgs;
 int fl_grouped_gemm_fp8(const FlGemmArgs* args, fl_stream_t stream);
 int fl_gemm_set_num_cus(int n);   /* deep_gemm.set_num_sms (srt/tbo/tbo_executor.py:129-134) */

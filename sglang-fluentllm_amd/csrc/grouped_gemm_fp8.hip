@@ -124,14 +124,20 @@ __global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void g
   const int li = lane & 31, lh = lane >> 5;
 
   // ---- tile -> (expert, token range, weight tile) ----
-  const int nt = blockIdx.x % p.n_tiles;
-  const int mt = blockIdx.x / p.n_tiles;
+  const int split = p.ksplit > 1 ? blockIdx.x % p.ksplit : 0;   // split-K: the k blocks of a tile over ksplit workgroups
+  const int tile = p.ksplit > 1 ? blockIdx.x / p.ksplit : blockIdx.x;
+  const int nt = tile % p.n_tiles;
+  const int mt = tile / p.n_tiles;
   int e = 0;
   long long row0 = 0;     // first row of the tile in A / out
   long long row_end = 0;  // one past the last valid row
   if (!locate_tile<BM>(p, gmeta, mt, e, row0, row_end)) return;
   const int n0 = nt * BN;
-  const int KB = p.K / BK;
+  const int KB_all = p.K / BK;
+  const int kb_per = (KB_all + p.ksplit - 1) / p.ksplit;
+  const int kb0 = split * kb_per;
+  const int KB = (kb0 + kb_per < KB_all ? kb0 + kb_per : KB_all) - kb0;   // k blocks of this workgroup: [kb0, kb0 + KB)
+  if (KB <= 0) return;
 
   // ---- per-lane DMA sources (k-invariant parts) ----
   // W piece (wave*4 + k): rows 8*(wave*4+k) + (lane>>3); LDS chunk position lane&7 holds source chunk (lane&7)^((r>>1)&7)
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void g
     const int r = wr + 8 * k;
     int n = n0 + r;
     n = n < p.N ? n : p.N - 1;
-    wsrc[k] = gW + ((long long)e * p.N + n) * p.K + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    wsrc[k] = gW + ((long long)e * p.N + n) * p.K + (((lane & 7) ^ ((r >> 1) & 7)) << 4) + (long long)kb0 * BK;
   }
   const uint8_t* asrc[MT];
 #pragma unroll
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void g
     const int r = (wave * MT + k) * 8 + (lane >> 3);   // row inside the token tile
     long long m = row0 + r;
     m = m < row_end ? m : row_end - 1;
-    asrc[k] = gA + m * p.K + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    asrc[k] = gA + m * p.K + (((lane & 7) ^ ((r >> 1) & 7)) << 4) + (long long)kb0 * BK;
   }
   constexpr int kAsPieces = Smem<MT>::kAsFloats / 64;
   const float* assrc[kAsPieces];
@@ -160,8 +166,8 @@ __global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void g
     long long m = row0 + k * 64 + lane;
     m = m < row_end ? m : row_end - 1;
     // masked mode: scales are indexed [group, row in group, kb]
-    assrc[k] = p.mode == kMasked ? gAs + (long long)e * p.as_stride_g + (m - (long long)e * p.rows_per_group) * p.as_stride_m
-                                 : gAs + m * p.as_stride_m;
+    assrc[k] = (p.mode == kMasked ? gAs + (long long)e * p.as_stride_g + (m - (long long)e * p.rows_per_group) * p.as_stride_m
+                                  : gAs + m * p.as_stride_m) + (long long)kb0 * p.as_stride_k;
   }
   // operand read offsets inside a 32-row x 128 B sub-tile: row li, 16-B chunk c = 4*s2 + 2*lh + e2 (s = 2*s2 + e2)
   int rb[4];
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void g
   for (int s = 0; s < kStages - 1; ++s)
     if (s < KB) issue_stage(s);
 
-  const float* wsrow = gWs + ((long long)e * ((p.N + BN - 1) / BN) + nt) * KB;
+  const float* wsrow = gWs + ((long long)e * ((p.N + BN - 1) / BN) + nt) * KB_all + kb0;
   // (a register-double-buffered variant of the 128-token tile was measured slower: 678 vs 833 TFLOP/s at T=16384)
   for (int kb = 0; kb < KB; ++kb) {
     const int st = kb % kStages;
@@ -212,6 +218,27 @@ __global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void g
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue: D^T[n, m] -> out[m, n] bf16; lane (m = li, half lh) holds n = 32*wave + 8g + 4lh + (0..3) ----
+  if (p.ksplit > 1) {   // split-K: f32 partials [split, M, N]; reduced + rounded by splitk_reduce_kernel
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const long long m = row0 + j * 32 + li;
+      if (m < row_end) {
+        float* prow = p.ws + ((long long)split * p.M + m) * p.N;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wave * 32 + 8 * g + 4 * lh;
+          if (n + 3 < p.N) {
+            *reinterpret_cast<float4*>(prow + n) = make_float4(acc[j][4 * g + 0], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+          } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+              if (n + x < p.N) prow[n + x] = acc[j][4 * g + x];
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const long long m = row0 + j * 32 + li;
@@ -232,6 +259,19 @@ __global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void g
       }
     }
   }
+}
+
+// out[m, n] = bf16(sum_s ws[s, m, n]); 4 consecutive columns per thread (N % 4 == 0)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, long long MN,
+                                                            uint16_t* __restrict__ out) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= MN) return;
+  float4 a = *reinterpret_cast<const float4*>(ws + i);
+  for (int s = 1; s < ksplit; ++s) {
+    const float4 b = *reinterpret_cast<const float4*>(ws + (long long)s * MN + i);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  *reinterpret_cast<uint2*>(out + i) = make_uint2(fl_pack_bf16(a.x, a.y), fl_pack_bf16(a.z, a.w));
 }
 
 int g_num_cus_limit = 0;   // deep_gemm.set_num_sms (tbo/tbo_executor.py:129-134): advisory on this path
@@ -272,7 +312,14 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
     const char* e = getenv("FLUENT_GEMM_BIG_MIN_ROWS");
     return e != nullptr ? atoll(e) : 192ll;
   }();
-  if (big_on && avg >= big_min && a->K >= 2 * BK && a->mode != kContiguous && (long long)a->N * a->K < (1ll << 32))
+  p.ksplit = 1;
+  p.ws = nullptr;
+  // (a dense problem with few 128-row tiles goes the split-K way below, not to the big tile: [256, K] x [2176, K] would
+  //  be 9 workgroups of 256 x 256)
+  const bool few_tiles = a->mode == kDense && a->workspace != nullptr &&
+                         ((a->M + 32 * mt - 1) / (32 * mt)) * (long long)p.n_tiles < 384;
+  if (!few_tiles && big_on && avg >= big_min && a->K >= 2 * BK && a->mode != kContiguous &&
+      (long long)a->N * a->K < (1ll << 32))
     return fl_gemm_launch_big(p, a->A, a->As, a->W, a->Ws, a->group_meta, (hipStream_t)stream);
   const int bm = 32 * mt;
   long long m_tiles;
@@ -280,7 +327,29 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
   else if (a->mode == kMasked) m_tiles = (long long)a->num_groups * ((a->rows_per_group + bm - 1) / bm);
   else m_tiles = (a->M + bm - 1) / bm;
   p.m_tiles_upper = (int)m_tiles;
-  const long long blocks = m_tiles * p.n_tiles;
+  long long blocks = m_tiles * p.n_tiles;
+  // few tiles for the chip (dense decode GEMMs: [T <= 256, K] x [N, K] has N/128 .. 2N/128 tiles): split the k blocks so
+  // that ~2 workgroups per CU stream the weights; f32 partials in the caller's workspace, one reduce kernel
+  p.ws = (float*)a->workspace;
+  if (few_tiles) {
+    // bytes-equivalent cost model: the weight stream runs at full rate only with >= one workgroup per CU, and every split
+    // writes + reads an f32 partial of the whole output: cost(ks) = W / min(1, tiles*ks/256) + 2*ks*M*N*4
+    const int KBt = a->K / BK;
+    const double wbytes = (double)a->N * a->K, pbytes = 8.0 * (double)a->M * a->N;
+    int best = 1;
+    double best_cost = wbytes / (blocks >= 256 ? 1.0 : (double)blocks / 256.0);
+    for (int ks = 2; ks <= KBt / 2; ++ks) {
+      if ((long long)ks * a->M * a->N * 4 > a->workspace_bytes) break;
+      const double par = (double)blocks * ks / 256.0;
+      const double cost = wbytes / (par >= 1.0 ? 1.0 : par) + pbytes * ks;
+      if (cost < best_cost) { best_cost = cost; best = ks; }
+    }
+    if (best > 1) {
+      const int per = (KBt + best - 1) / best;
+      p.ksplit = (KBt + per - 1) / per;                               // no empty splits
+      blocks *= p.ksplit;
+    }
+  }
   FL_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fl_grouped_gemm_fp8: grid too large");
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -291,5 +360,10 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
   else
     grouped_gemm_fp8_kernel<4><<<grid, block, 0, s>>>(p, (const uint8_t*)a->A, a->As, (const uint8_t*)a->W, a->Ws, a->group_meta);
   FL_CHECK_LAUNCH("grouped_gemm_fp8_kernel");
+  if (p.ksplit > 1) {
+    const long long MN = a->M * (long long)a->N;
+    splitk_reduce_kernel<<<dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, s>>>(p.ws, p.ksplit, MN, p.out);
+    FL_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
   return FL_OK;
 }

@@ -17,6 +17,8 @@ struct GemmParams {
   long long as_stride_m, as_stride_k, as_stride_g;   // element strides of As (g: masked mode only)
   long long rows_per_group;             // masked mode: padded rows per group
   uint16_t* out;
+  int ksplit;                           // > 1: the k blocks are split over ksplit workgroups per tile, f32 partials in ws
+  float* ws;                            // [ksplit, M, N] f32
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

@@ -27,6 +27,7 @@ class FlGemmArgs(ctypes.Structure):
         ("A", ctypes.c_void_p), ("As", ctypes.c_void_p),
         ("as_stride_m", ctypes.c_int64), ("as_stride_k", ctypes.c_int64), ("as_stride_g", ctypes.c_int64),
         ("W", ctypes.c_void_p), ("Ws", ctypes.c_void_p), ("out", ctypes.c_void_p), ("group_meta", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
     ]
 
 
@@ -66,6 +67,19 @@ def get_col_major_tma_aligned_tensor(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+_SPLITK_MAX_ROWS = 1024
+_SPLITK_BYTES = 64 << 20
+_splitk_ws = {}
+
+
+def _splitk_workspace(device):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr(device))
+    ws = _splitk_ws.get(key)
+    if ws is None:
+        ws = _splitk_ws[key] = torch.empty(_SPLITK_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
 def _gemm(mode, lhs, rhs, out, meta, rows_per_group=0, expected_m=0):
     A, As = lhs
     W, Ws = rhs
@@ -101,6 +115,10 @@ def _gemm(mode, lhs, rhs, out, meta, rows_per_group=0, expected_m=0):
     if meta is not None:
         _req(meta.is_cuda and meta.dtype == torch.int32 and meta.is_contiguous(), "group metadata must be int32 on device")
         a.group_meta = meta.data_ptr()
+    if mode == MODE_DENSE and a.M <= _SPLITK_MAX_ROWS:
+        # few output tiles (decode projections): scratch for the library's split-K, one buffer per (device, stream)
+        ws = _splitk_workspace(A.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     check(lib.fl_grouped_gemm_fp8(ctypes.byref(a), stream_ptr(A.device)), "fl_grouped_gemm_fp8")
 
 
