@@ -314,8 +314,18 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
   }();
   p.ksplit = 1;
   p.ws = nullptr;
-  // (a dense problem with few 128-row tiles goes the split-K way below, not to the big tile: [256, K] x [2176, K] would
-  //  be 9 workgroups of 256 x 256)
+  // Dense GEMMs with few rows (decode projections; a workspace is present): the token-tile height follows the weight
+  // bytes — measured (tools/bench_dense.py): <= 8 MB 32-token tiles, <= 32 MB 64-token tiles (3-stage rings, 2
+  // workgroups per CU), else 128-token tiles (fewer re-reads of W through L2); split-K fills the chip
+  static const int dense_mt = [] {   // experiment knob
+    const char* e = getenv("FLUENT_GEMM_DENSE_MT");
+    return e != nullptr ? atoi(e) : 0;
+  }();
+  if (a->mode == kDense && a->workspace != nullptr) {
+    const long long wb = (long long)a->N * a->K;
+    const int want = dense_mt > 0 ? dense_mt : (wb <= (8ll << 20) ? 1 : (wb <= (32ll << 20) ? 2 : 4));
+    if (mt > want) mt = want;
+  }
   const bool few_tiles = a->mode == kDense && a->workspace != nullptr &&
                          ((a->M + 32 * mt - 1) / (32 * mt)) * (long long)p.n_tiles < 384;
   if (!few_tiles && big_on && avg >= big_min && a->K >= 2 * BK && a->mode != kContiguous &&
