@@ -168,6 +168,8 @@ int fl_ep_gather_rows(const void* src, int64_t src_rows, const int32_t* idx, int
                       int64_t dst_rows, fl_stream_t stream);   /* dst[i] = src[idx[i]] */
 int fl_ep_scatter_rows(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int hidden, void* dst,
                        int64_t dst_rows, fl_stream_t stream);  /* dst[idx[i]] = src[i] */
+int fl_ep_send_rows(const void* x, int64_t num_tokens, const int32_t* send_slot /*[num_pairs]*/, int64_t num_pairs, int top_k,
+                    int hidden, void* send_buf, int64_t send_rows, fl_stream_t stream);  /* send_buf[send_slot[p]] = x[p / top_k] */
 int fl_ep_combine(const void* ret_rows, int64_t num_ret_rows, const int32_t* send_slot, const float* weights,
                   int64_t num_tokens, int top_k, int hidden, void* out, fl_stream_t stream);
 

@@ -66,46 +66,90 @@ __global__ __launch_bounds__(256) void ep_sort_kernel(const int32_t* __restrict_
   }
 }
 
-// one wave per row; hidden*2 bytes per row, 16 B per lane per step
+// one workgroup per row (hidden*2 bytes), every thread's 16-B loads issued before its stores: a decode step moves a few
+// hundred rows, so the depth of one row's copy, not the row count, sets the time
 template <bool kScatter>
 __global__ __launch_bounds__(256) void ep_rows_kernel(const uint16_t* __restrict__ src, const int32_t* __restrict__ idx,
                                                       long long n, int hidden, long long src_rows, long long dst_rows,
-                                                      uint16_t* __restrict__ dst) {
-  const int lane = threadIdx.x & 63;
-  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n) return;
+                                                      uint16_t* __restrict__ dst, int src_div) {
+  const long long i = blockIdx.x;
   const long long j = idx[i];
-  const long long s = kScatter ? i : j, d = kScatter ? j : i;
+  const long long s = kScatter ? (long long)((unsigned)i / (unsigned)src_div) : j, d = kScatter ? j : i;   // src_div = top_k: pair i carries token i / top_k
   if (s < 0 || s >= src_rows || d < 0 || d >= dst_rows) return;
-  const uint4* sp = reinterpret_cast<const uint4*>(src + s * hidden);
-  uint4* dp = reinterpret_cast<uint4*>(dst + d * hidden);
-  for (int c = lane; c < hidden / 8; c += 64) dp[c] = sp[c];
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4* sp = reinterpret_cast<const u32x4*>(src + s * hidden);
+  u32x4* dp = reinterpret_cast<u32x4*>(dst + d * hidden);
+  const int nc = hidden / 8;
+  for (int c0 = threadIdx.x; c0 < nc; c0 += 4 * 256) {
+    // loads are unconditional on a clamped column (a predicated load into an array makes hipcc stage it through LDS
+    // with a full wait per load); only the stores are predicated
+    u32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = sp[c0 + u * 256 < nc ? c0 + u * 256 : c0];
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));   // all four loads in flight before the first store
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (c0 + u * 256 < nc) dp[c0 + u * 256] = v[u];
+  }
 }
 
+// One WORKGROUP per token (a decode step has a few dozen tokens per rank: one wave per token looping over the hidden
+// dimension with its slot / weight / row loads inside the loop was 112 dependent round trips, 62 us for 32 tokens).
+// Slots and weights are staged once, the top_k row loads of a 16-B column group are issued together; the sum runs in
+// expert order k = 0 .. top_k-1 in fp32 as before.
 __global__ __launch_bounds__(256) void ep_combine_kernel(const uint16_t* __restrict__ ret, const int32_t* __restrict__ slot,
                                                          const float* __restrict__ w, long long t_count, int top_k,
                                                          int hidden, long long ret_rows, uint16_t* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= t_count) return;
-  for (int c = lane; c < hidden / 8; c += 64) {
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < top_k; ++k) {
-      const long long s = slot[t * top_k + k];
-      if (s < 0 || s >= ret_rows) continue;
-      const float wk = w[t * top_k + k];
-      const uint4 v = reinterpret_cast<const uint4*>(ret + s * hidden)[c];
-      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[2 * q] += wk * __uint_as_float(u[q] << 16);
-        acc[2 * q + 1] += wk * __uint_as_float(u[q] & 0xffff0000u);
-      }
+  __shared__ long long s_slot[64];
+  __shared__ float s_w[64];
+  const int tid = threadIdx.x;
+  const long long t = blockIdx.x;
+  for (int k0 = 0; k0 < top_k; k0 += 64) {   // (top_k > 64: in rounds; the partial sums stay in registers per column group)
+    __syncthreads();
+    if (tid < 64 && k0 + tid < top_k) {
+      const long long sl = slot[t * top_k + k0 + tid];
+      const bool ok = sl >= 0 && sl < ret_rows;
+      s_slot[tid] = ok ? sl : -1;
+      s_w[tid] = ok ? w[t * top_k + k0 + tid] : 0.f;
     }
-    uint32_t o[4];
+    __syncthreads();
+    const int kn = top_k - k0 < 64 ? top_k - k0 : 64;
+    // grid.y covers the row in chunks of 256 column groups: a decode step has few tokens, so the columns fill the chip
+    for (int c = blockIdx.y * 256 + tid; c < hidden / 8; c += 256 * gridDim.y) {
+      float acc[8];
+      if (k0 == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = (uint32_t)fl_f32_to_bf16(acc[2 * q]) | ((uint32_t)fl_f32_to_bf16(acc[2 * q + 1]) << 16);
-    reinterpret_cast<uint4*>(out + t * hidden)[c] = make_uint4(o[0], o[1], o[2], o[3]);
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+      } else {   // continue a previous round: read back what it stored (bf16-rounded only in the last round otherwise)
+        const uint4 v = reinterpret_cast<const uint4*>(out + t * hidden)[c];
+        const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc[2 * q] = __uint_as_float(u[q] << 16); acc[2 * q + 1] = __uint_as_float(u[q] & 0xffff0000u); }
+      }
+      for (int kb = 0; kb < kn; kb += 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // unconditional load (empty slot: row 0, skipped below) - see ep_rows_kernel
+          const long long sl = kb + j < kn ? s_slot[kb + j] : -1;
+          v[j] = reinterpret_cast<const uint4*>(ret + (sl >= 0 ? sl : 0) * hidden)[c];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (kb + j < kn && s_slot[kb + j] >= 0) {
+            const float wk = s_w[kb + j];
+            const uint32_t u[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              acc[2 * q] += wk * __uint_as_float(u[q] << 16);
+              acc[2 * q + 1] += wk * __uint_as_float(u[q] & 0xffff0000u);
+            }
+          }
+        }
+      }
+      reinterpret_cast<uint4*>(out + t * hidden)[c] = make_uint4(fl_pack_bf16(acc[0], acc[1]), fl_pack_bf16(acc[2], acc[3]),
+                                                                fl_pack_bf16(acc[4], acc[5]), fl_pack_bf16(acc[6], acc[7]));
+    }
   }
 }
 
@@ -134,8 +178,8 @@ extern "C" int fl_ep_gather_rows(const void* src, int64_t src_rows, const int32_
                                  int64_t dst_rows, fl_stream_t stream) {
   FL_CHECK_ARG(src && idx && dst && hidden % 8 == 0, "fl_ep_gather_rows: bad args");
   if (n == 0) return FL_OK;
-  ep_rows_kernel<false><<<dim3((unsigned)((n + 3) / 4)), 256, 0, (hipStream_t)stream>>>(
-      (const uint16_t*)src, idx, n, hidden, src_rows, dst_rows, (uint16_t*)dst);
+  ep_rows_kernel<false><<<dim3((unsigned)n), 256, 0, (hipStream_t)stream>>>(
+      (const uint16_t*)src, idx, n, hidden, src_rows, dst_rows, (uint16_t*)dst, 1);
   FL_CHECK_LAUNCH("fl_ep_gather_rows");
   return FL_OK;
 }
@@ -144,9 +188,19 @@ extern "C" int fl_ep_scatter_rows(const void* src, int64_t src_rows, const int32
                                   int64_t dst_rows, fl_stream_t stream) {
   FL_CHECK_ARG(src && idx && dst && hidden % 8 == 0, "fl_ep_scatter_rows: bad args");
   if (n == 0) return FL_OK;
-  ep_rows_kernel<true><<<dim3((unsigned)((n + 3) / 4)), 256, 0, (hipStream_t)stream>>>(
-      (const uint16_t*)src, idx, n, hidden, src_rows, dst_rows, (uint16_t*)dst);
+  ep_rows_kernel<true><<<dim3((unsigned)n), 256, 0, (hipStream_t)stream>>>(
+      (const uint16_t*)src, idx, n, hidden, src_rows, dst_rows, (uint16_t*)dst, 1);
   FL_CHECK_LAUNCH("fl_ep_scatter_rows");
+  return FL_OK;
+}
+
+extern "C" int fl_ep_send_rows(const void* x, int64_t num_tokens, const int32_t* send_slot, int64_t num_pairs, int top_k,
+                               int hidden, void* send_buf, int64_t send_rows, fl_stream_t stream) {
+  FL_CHECK_ARG(x && send_slot && send_buf && hidden % 8 == 0 && top_k >= 1, "fl_ep_send_rows: bad args");
+  if (num_pairs == 0) return FL_OK;
+  ep_rows_kernel<true><<<dim3((unsigned)num_pairs), 256, 0, (hipStream_t)stream>>>(
+      (const uint16_t*)x, send_slot, num_pairs, hidden, num_tokens, send_rows, (uint16_t*)send_buf, top_k);
+  FL_CHECK_LAUNCH("fl_ep_send_rows");
   return FL_OK;
 }
 
@@ -154,7 +208,7 @@ extern "C" int fl_ep_combine(const void* ret_rows, int64_t num_ret_rows, const i
                              int64_t num_tokens, int top_k, int hidden, void* out, fl_stream_t stream) {
   FL_CHECK_ARG(ret_rows && send_slot && weights && out && hidden % 8 == 0 && top_k >= 1, "fl_ep_combine: bad args");
   if (num_tokens == 0) return FL_OK;
-  ep_combine_kernel<<<dim3((unsigned)((num_tokens + 3) / 4)), 256, 0, (hipStream_t)stream>>>(
+  ep_combine_kernel<<<dim3((unsigned)num_tokens, (unsigned)((hidden / 8 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
       (const uint16_t*)ret_rows, send_slot, weights, num_tokens, top_k, hidden, num_ret_rows, (uint16_t*)out);
   FL_CHECK_LAUNCH("fl_ep_combine");
   return FL_OK;

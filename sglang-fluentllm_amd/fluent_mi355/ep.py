@@ -27,8 +27,10 @@ class HipRowOps:
         lib.fl_ep_sort.argtypes = [vp, i64, i32, vp, vp, vp]
         lib.fl_ep_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
         lib.fl_ep_scatter_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
+        lib.fl_ep_send_rows.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp]
         lib.fl_ep_combine.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp]
-        for n in ("fl_ep_route", "fl_ep_sort", "fl_ep_gather_rows", "fl_ep_scatter_rows", "fl_ep_combine"):
+        for n in ("fl_ep_route", "fl_ep_sort", "fl_ep_gather_rows", "fl_ep_scatter_rows", "fl_ep_send_rows",
+                  "fl_ep_combine"):
             getattr(lib, n).restype = i32
 
     def route(self, indices, experts_per_rank, world, cap, send_slot, send_eid):
@@ -46,6 +48,11 @@ class HipRowOps:
     def scatter(self, src, idx, n, dst):
         self._check(self._lib.fl_ep_scatter_rows(src.data_ptr(), src.shape[0], idx.data_ptr(), n, src.shape[1], dst.data_ptr(),
                                                  dst.shape[0], self._stream(src.device)), "fl_ep_scatter_rows")
+
+    def send(self, x, send_slot, top_k, send_buf):
+        """send_buf[send_slot[p]] = x[p // top_k] for every (token, expert) pair p with a slot"""
+        self._check(self._lib.fl_ep_send_rows(x.data_ptr(), x.shape[0], send_slot.data_ptr(), send_slot.numel(), top_k, x.shape[1],
+                                              send_buf.data_ptr(), send_buf.shape[0], self._stream(x.device)), "fl_ep_send_rows")
 
     def combine(self, ret, send_slot, weights, out, top_k):
         self._check(self._lib.fl_ep_combine(ret.data_ptr(), ret.shape[0], send_slot.data_ptr(), weights.data_ptr(),
@@ -71,11 +78,12 @@ class AllToAll:
         self.row_ops = row_ops if row_ops is not None else HipRowOps()
         self._state = None
 
-    def _a2a(self, out, inp):
+    def _a2a(self, inp):
         if self.world == 1:
-            out.copy_(inp)
-        else:
-            dist.all_to_all_single(out, inp, group=self.group)   # equal splits: world slabs of `cap` rows
+            return inp                                            # one rank: the slab it sends is the slab it receives
+        out = torch.empty_like(inp)
+        dist.all_to_all_single(out, inp, group=self.group)       # equal splits: world slabs of `cap` rows
+        return out
 
     def dispatch(self, out_exclusive_sum, out_expert_x, dp_x, indices, num_global_tokens):
         t = dp_x.shape[0]
@@ -86,16 +94,10 @@ class AllToAll:
         send_slot = torch.empty(idx.numel(), dtype=torch.int32, device=dev)
         send_eid = torch.empty(S, dtype=torch.int32, device=dev)
         self.row_ops.route(idx, self.experts_per_rank, self.world, self.cap, send_slot, send_eid)
-        # rows of pair p = (token p // top_k): gather through a pair->token index so that one kernel serves both uses
-        send_buf = torch.empty(S, self.hidden, dtype=dp_x.dtype, device=dev)
-        pair_tok = (torch.arange(idx.numel(), device=dev, dtype=torch.int32) // self.top_k)
-        rows = torch.empty(idx.numel(), self.hidden, dtype=dp_x.dtype, device=dev)
-        self.row_ops.gather(dp_x, pair_tok, idx.numel(), rows)
-        self.row_ops.scatter(rows, send_slot, idx.numel(), send_buf)
-        recv_buf = torch.empty_like(send_buf)
-        recv_eid = torch.empty_like(send_eid)
-        self._a2a(recv_buf, send_buf)
-        self._a2a(recv_eid, send_eid)
+        send_buf = torch.empty(S, self.hidden, dtype=dp_x.dtype, device=dev)   # empty slots: never read (send_eid = -1)
+        self.row_ops.send(dp_x.contiguous(), send_slot, self.top_k, send_buf)
+        recv_buf = self._a2a(send_buf)
+        recv_eid = self._a2a(send_eid)
         order = torch.empty(S, dtype=torch.int32, device=dev)
         self.row_ops.sort(recv_eid, self.experts_per_rank, order, out_exclusive_sum)
         n_out = min(out_expert_x.shape[0], S)
@@ -108,9 +110,9 @@ class AllToAll:
             raise RuntimeError("combine() without a preceding dispatch()")
         send_slot, order, n_out, S = self._state
         dev = expert_y.device
-        back = torch.zeros(S, self.hidden, dtype=expert_y.dtype, device=dev)
+        # rows nobody computed (out_expert_x shorter than the slab) must come back as zeros, not as stale memory
+        back = (torch.empty if n_out >= S else torch.zeros)(S, self.hidden, dtype=expert_y.dtype, device=dev)
         self.row_ops.scatter(expert_y, order, n_out, back)
-        ret = torch.empty_like(back)
-        self._a2a(ret, back)
+        ret = self._a2a(back)
         self.row_ops.combine(ret, send_slot, weights.to(torch.float32).contiguous(), out_tokens, self.top_k)
         return out_tokens

@@ -35,6 +35,11 @@ class TorchRowOps:
         ok = (i >= 0) & (i < dst.shape[0])
         dst[i[ok]] = src[:n][ok]
 
+    def send(self, x, send_slot, top_k, send_buf):
+        s = send_slot.long()
+        ok = (s >= 0) & (s < send_buf.shape[0])
+        send_buf[s[ok]] = x[torch.arange(s.numel())[ok] // top_k]
+
     def combine(self, ret, send_slot, weights, out, top_k):
         s = send_slot.view(-1, top_k).long()
         ok = (s >= 0).unsqueeze(-1)

@@ -14,6 +14,7 @@ import flash_mla_fp8 as fm
 import deep_gemm, flashinfer
 import flashinfer.comm as comm
 from eps.executor import silu
+from eps.fast_ep import AllToAll
 from fluent_mi355.gemm import per_token_group_quant_fp8
 
 dev = torch.device("cuda:0")
@@ -45,6 +46,17 @@ for l in range(LAYERS):
 x = torch.randn(BS, HID, device=dev, generator=g).to(torch.bfloat16)
 res = torch.randn(BS, HID, device=dev, generator=g).to(torch.bfloat16)
 attn_o = torch.randn(BS, 16 * 128, device=dev, generator=g).to(torch.bfloat16)     # stands in for the absorbed-V output
+# EP dispatch / combine at world 1 (the exchange is a copy; the route / sort / gather / scatter / weighted-combine kernels
+# run as in the 8-rank job): this rank's BS/WORLD tokens, top-8 over the 32 local experts
+T_LOC = BS // WORLD
+EP_OPS = os.environ.get("EP_OPS", "1") == "1"   # the device side of eps.fast_ep dispatch/combine (world 1: no exchange)
+a2a = AllToAll(TOPK, EL, HID, T_LOC, None)
+dp_x = torch.randn(T_LOC, HID, device=dev, generator=g).to(torch.bfloat16)
+route = torch.stack([torch.randperm(EL, device=dev, generator=g)[:TOPK] for _ in range(T_LOC)]).to(torch.int32)
+route_w = torch.rand(T_LOC, TOPK, device=dev, generator=g)
+a2a_ex = torch.empty(EL + 1, dtype=torch.int32, device=dev)
+a2a_rows = torch.zeros(T_LOC * TOPK, HID, dtype=torch.bfloat16, device=dev)
+a2a_out = torch.empty(T_LOC, HID, dtype=torch.bfloat16, device=dev)
 # routed rows of this rank: BS*TOPK/WORLD rows spread over its 32 experts
 M = BS * TOPK // WORLD
 counts = torch.bincount(torch.randint(0, EL, (M,), device=dev, generator=g), minlength=EL)
@@ -75,11 +87,13 @@ def attention(l):
     deep_gemm.gemm_fp8_fp8_bf16_nt((oq, os_), W[l]["o"], buf["o"])
 def moe(l):
     norm_quant(l, W[l]["gamma2"])
+    if EP_OPS: a2a.dispatch(out_exclusive_sum=a2a_ex, out_expert_x=a2a_rows, dp_x=dp_x, indices=route, num_global_tokens=T_LOC)
     flashinfer.quantization.quant_1x128(rows, buf["xq"], buf["xs"], ex, EL, (M + 3) // 4 * 4, mp, HID)
     deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset((buf["xq"], buf["xs"]), W[l]["w13"], buf["gate_up"], ex, use_pdl=True)
     a = silu(buf["gate_up"], ex, M)
     flashinfer.quantization.quant_1x128(a, buf["dq"], buf["ds"], ex, EL, (M + 3) // 4 * 4, mp, INTER)
     deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset((buf["dq"], buf["ds"]), W[l]["w2"], buf["down"], ex, use_pdl=True)
+    if EP_OPS: a2a.combine(out_tokens=a2a_out, weights=route_w, expert_y=buf["down"], num_global_tokens=T_LOC)
 
 def timed(fn):
     for l in range(LAYERS): fn(l)
