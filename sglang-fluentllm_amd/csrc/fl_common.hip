@@ -24,6 +24,16 @@ bool fl_mla_use_x() {
   }();
   return on;
 }
+int fl_mla_x_rows_per_wg() {
+  // query rows one workgroup of mla_decode_fp8_x.hip owns when a request has more than 64: 128 (one workgroup streams a
+  // KV part once for all rows; long requests are split along KV) or, with FLUENT_MLA_X_ROWS=64, 64 (row groups of one
+  // request run as neighbouring workgroups of one XCD and share the KV stream through its L2; fewer KV splits)
+  static const int rows = [] {
+    const char* e = getenv("FLUENT_MLA_X_ROWS");
+    return (e != nullptr && atoi(e) == 64) ? 64 : 128;
+  }();
+  return rows;
+}
 extern "C" int fl_version(void) { return 100; }
 
 extern "C" int fl_device_cu_count(int device, int* cu_count) {

@@ -188,8 +188,21 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big_kernel(const Gemm
         b1 = ld8(sa + (j + 1) * (32 * BK), 1);
         sc = sas[32 * (j + 1) + li] * ws;
       }
+#ifndef FL_GEMM_STAGGER
+#define FL_GEMM_STAGGER 1
+#endif
+#if FL_GEMM_STAGGER >= 0
+      // wave pairs take turns at the CU's vector-memory path: waves 2s, 2s+1 issue their whole refill (9 pieces) beside
+      // tile s = 0..3 instead of all eight waves issuing one piece beside every tile (+2.5 % on w13 at T=16384, w2 equal;
+      // one wave per tile over all 8 tiles: -1.5 % — the late refills land after the next barrier)
+      if (t == (wave >> FL_GEMM_STAGGER)) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dma_piece(kn, k);
+      }
+#else
       dma_piece(kn, t);
       if (t == 7) dma_piece(kn, 8);
+#endif
       if (t > 0) {
         const int tp = t - 1, jp = tp >> 1, ip = tp & 1;
         asm volatile("s_nop 3" : "+v"(part[tp & 1]));

@@ -982,7 +982,7 @@ __global__ __launch_bounds__(64 * (NWC + (NWC == 4 ? 0 : 2)), 1) void mla_decode
 int fl_mla_decode_fp8_x_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipStream_t stream) {
   Params p = p_in;
   // compute waves per workgroup from the query rows per request (fl_mla_num_parts sizes the part count with the same rule)
-  const int nwc = p.rows <= 64 ? 2 : 4;   // (at most 32 rows: mla_decode_fp8.hip, see its dispatcher)
+  const int nwc = (p.rows <= 64 || fl_mla_x_rows_per_wg() == 64) ? 2 : 4;   // (at most 32 rows: mla_decode_fp8.hip, see its dispatcher)
   p.row_groups = (p.rows + 32 * nwc - 1) / (32 * nwc);
   const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(64 * (nwc + (nwc == 4 ? 0 : 2)));
   p.partial_bf16 = 1;   // split partials travel as bf16 rows (half the bytes of the f32 layout of mla_decode_fp8.hip)
