@@ -146,8 +146,10 @@ def main():
     torch.cuda.synchronize()
 
     def step():
+        # K3 once per decode step, as the reference's backend does in init_forward_metadata (flashmla_backend.py:307-321)
+        m_step, ns_step = fm.get_mla_metadata(wl["seqlens"], S_Q * H, 1)
         for l in range(layers):
-            layer_call(fm, wl, l, meta, ns)
+            layer_call(fm, wl, l, m_step, ns_step)
 
     # eager warm-up (also sizes the caching allocator), then capture one step in a hipGraph like the reference's
     # decode path (model_executor/cuda_graph_runner.py:433-434)
