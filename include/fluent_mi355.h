@@ -173,6 +173,16 @@ int fl_ep_send_rows(const void* x, int64_t num_tokens, const int32_t* send_slot 
 int fl_ep_combine(const void* ret_rows, int64_t num_ret_rows, const int32_t* send_slot, const float* weights,
                   int64_t num_tokens, int top_k, int hidden, void* out, fl_stream_t stream);
 
+/* ---- R1: flashinfer.moe_fused_gate as called by biased_grouped_topk_gpu (srt/layers/moe/topk.py:709-733);
+ * semantics of its torch statement biased_grouped_topk_impl (topk.py:596-663), renormalize=True, no fused shared
+ * experts.  logits f32 [T, E] (E = 64*2^k <= 1024), bias f32 [E]; num_expert_group a power of two <= 64;
+ * num_token_non_padded: optional DEVICE int32 scalar (rows at or beyond it get ids -1, topk.py:673-680).
+ * Rows of the outputs are ordered by descending (sigmoid + bias); ties -> lower expert id. ---- */
+int fl_moe_fused_gate(const float* logits, const float* bias, int64_t num_tokens, int num_experts, int num_expert_group,
+                      int topk_group, int topk, float routed_scaling_factor, int apply_routed_scaling_factor_on_output,
+                      const int32_t* num_token_non_padded, float* topk_weights /*[T, topk]*/,
+                      int32_t* topk_ids /*[T, topk]*/, fl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

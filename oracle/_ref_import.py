@@ -90,3 +90,18 @@ def load_method_from_source(path, cls_name, method_name, namespace):
                     exec(compile(ast.Module(body=[item], type_ignores=[]), path, "exec"), namespace)
                     return namespace[method_name]
     raise KeyError(f"{cls_name}.{method_name} not found in {path}")
+
+
+def load_function_from_source(path, func_name, namespace):
+    """exec() one module-level function of a reference file (whose module does not import under stubs) in `namespace`,
+    WITHOUT its decorators (e.g. @torch.compile: the eager function is the statement we want); returns it."""
+    import ast
+
+    with open(path) as f:
+        tree = ast.parse(f.read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == func_name:
+            node.decorator_list = []
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), namespace)
+            return namespace[func_name]
+    raise KeyError(f"{func_name} not found in {path}")

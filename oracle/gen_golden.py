@@ -222,8 +222,39 @@ def gen_rmsnorm():
     print("rmsnorm", sorted(out)[:3])
 
 
+def gen_router():
+    """biased_grouped_topk_impl (moe/topk.py:596-663), the torch statement behind `moe_fused_gate`, run eagerly from the
+    reference's own source: DeepSeek-V3 routing (256 experts, 8 groups, top-4 groups, top-8, scaling 2.5) + smaller shapes."""
+    import typing
+
+    ns = {"torch": torch, "Optional": typing.Optional, "ExpertLocationDispatchInfo": object,
+          "topk_ids_logical_to_physical": lambda ids, info: ids}
+    path = "/root/reference/python/sglang/srt/layers/moe/topk.py"
+    ns["_mask_topk_ids_padded_region"] = _ref_import.load_function_from_source(path, "_mask_topk_ids_padded_region", ns)
+    impl = _ref_import.load_function_from_source(path, "biased_grouped_topk_impl", ns)
+    g = torch.Generator().manual_seed(41)
+    out = {}
+    for name, T, E, G, TG, K, scale, on_out, npad in (("dsv3", 37, 256, 8, 4, 8, 2.5, True, None),
+                                                       ("dsv3_noscale", 16, 256, 8, 4, 8, 2.5, False, 11),
+                                                       ("e64", 9, 64, 4, 2, 6, 1.0, True, None),
+                                                       ("e128_g1", 5, 128, 1, 1, 8, 1.5, True, None)):
+        logits = torch.randn(T, E, generator=g) * 2
+        bias = torch.randn(E, generator=g) * 0.1
+        n = None if npad is None else torch.tensor(npad)
+        w, ids = impl(torch.empty(T, 1), logits, bias, K, True, G, TG, 0, scale, n, None, on_out)
+        out.update({f"{name}_logits": logits.numpy(), f"{name}_bias": bias.numpy(), f"{name}_w": w.numpy(),
+                    f"{name}_ids": ids.numpy().astype(np.int32),
+                    f"{name}_cfg": np.array([G, TG, K, int(on_out), -1 if npad is None else npad], np.int32),
+                    f"{name}_scale": np.array([scale], np.float32)})
+    np.savez_compressed(os.path.join(OUT, "router_biased_grouped_topk.npz"), **out)
+    print("router", sorted(k for k in out if k.endswith("_ids")))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--only-router" in sys.argv:
+        gen_router()
+        sys.exit(0)
     if "--only-rmsnorm" in sys.argv:
         gen_rmsnorm()
         sys.exit(0)
@@ -232,4 +263,5 @@ if __name__ == "__main__":
     gen_alloc()
     gen_gemm()
     gen_rmsnorm()
+    gen_router()
     print("golden written to", OUT)

@@ -127,3 +127,33 @@ def test_rmsnorm_oracle_matches_reference_golden():
         # the fused statement with one piece and a residual is the same arithmetic
         y2, r2 = norm_ref.fused_add_rmsnorm(x.unsqueeze(0), None, r, w, 1e-6)
         assert torch.equal(y2, y) and torch.equal(r2, ro)
+
+
+ROUTER_CASES = ("dsv3", "dsv3_noscale", "e64", "e128_g1")
+
+
+def router_case(g, name):
+    G, TG, K, on_out, npad = (int(v) for v in g[name + "_cfg"])
+    return dict(logits=g[name + "_logits"], bias=g[name + "_bias"], G=G, TG=TG, K=K, on_out=bool(on_out),
+                npad=None if npad < 0 else npad, scale=float(g[name + "_scale"][0]), w=g[name + "_w"], ids=g[name + "_ids"])
+
+
+def assert_router_rows_equal(w, ids, w_ref, ids_ref, npad, tol=2e-6):
+    """torch.topk(sorted=False) leaves the order inside a row unspecified: compare rows as {expert: weight} maps; padded
+    rows (ids -1, topk.py:673-680) only by their ids."""
+    o, o_ref = np.argsort(ids, 1, kind="stable"), np.argsort(ids_ref, 1, kind="stable")
+    assert np.array_equal(np.take_along_axis(ids, o, 1), np.take_along_axis(ids_ref, o_ref, 1))
+    live = slice(None) if npad is None else slice(0, npad)
+    assert np.abs(np.take_along_axis(w, o, 1)[live] - np.take_along_axis(w_ref, o_ref, 1)[live]).max() < tol
+
+
+def test_router_oracle_matches_reference_golden():
+    """oracle.router_ref.biased_grouped_topk ≡ the reference's biased_grouped_topk_impl (moe/topk.py:596-663) run from its
+    own source: same expert sets (bit-exact ids), weights within 2e-6 (float32 sigmoid)."""
+    from oracle import router_ref
+
+    g = load_golden("router_biased_grouped_topk.npz")
+    for name in ROUTER_CASES:
+        c = router_case(g, name)
+        w, ids = router_ref.biased_grouped_topk(c["logits"], c["bias"], c["G"], c["TG"], c["K"], c["scale"], c["on_out"], c["npad"])
+        assert_router_rows_equal(w, ids, c["w"], c["ids"], c["npad"])
