@@ -183,6 +183,16 @@ int fl_moe_fused_gate(const float* logits, const float* bias, int64_t num_tokens
                       const int32_t* num_token_non_padded, float* topk_weights /*[T, topk]*/,
                       int32_t* topk_ids /*[T, topk]*/, fl_stream_t stream);
 
+/* ---- R2: flashinfer.apply_rope_with_cos_sin_cache_inplace as RotaryEmbedding.forward_cuda calls it
+ * (srt/layers/rotary_embedding.py:203-218) on q_pe / k_pe of the MLA path (models/deepseek_v2.py:646-647,695-696).
+ * q bf16 [T, Hq, >=rotary_dim] and k bf16 [T, Hk, >=rotary_dim] rotated IN PLACE over their first rotary_dim elements
+ * (element strides given, last dim contiguous, rows 16-B aligned); positions int64 [T]; cos_sin_cache f32
+ * [max_position, rotary_dim] = cos | sin halves (:141-149,791-802).  fp32 arithmetic of forward_native (:804-846),
+ * bit-exact.  is_neox: rotate halves (:50-53), else neighbouring pairs (:56-60, DeepSeek). ---- */
+int fl_rope_inplace(const int64_t* positions, int64_t num_tokens, void* q, int64_t q_stride_token, int64_t q_stride_head,
+                    int num_q_heads, void* k, int64_t k_stride_token, int64_t k_stride_head, int num_k_heads,
+                    const float* cos_sin_cache, int64_t max_position, int rotary_dim, int is_neox, fl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -250,8 +250,54 @@ def gen_router():
     print("router", sorted(k for k in out if k.endswith("_ids")))
 
 
+def gen_rope():
+    """DeepseekScalingRotaryEmbedding (layers/rotary_embedding.py:719-846) run from the reference's own source: the YaRN
+    cos/sin cache (fp32, as the CUDA path keeps it, :113-115) of a reduced config and forward_native on bf16 q_pe / k_pe —
+    GPT-J style (DeepSeek-V3: is_neox_style=False, deepseek_v2.py:492-499) and NeoX style."""
+    import math
+    import typing
+
+    path = "/root/reference/python/sglang/srt/layers/rotary_embedding.py"
+    ns = {"torch": torch, "math": math, "Optional": typing.Optional, "Tuple": typing.Tuple, "Union": typing.Union}
+    for fn in ("_rotate_neox", "_rotate_gptj", "_yarn_find_correction_dim", "_yarn_find_correction_range",
+               "_yarn_linear_ramp_mask", "yarn_get_mscale"):
+        ns[fn] = _ref_import.load_function_from_source(path, fn, ns)
+    cls = "DeepseekScalingRotaryEmbedding"
+    inv_freq = _ref_import.load_method_from_source(path, cls, "_compute_inv_freq", ns)
+    cache_fn = _ref_import.load_method_from_source(path, cls, "_compute_cos_sin_cache", ns)
+    fwd = _ref_import.load_method_from_source(path, cls, "forward_native", ns)
+
+    class Rope:
+        _compute_inv_freq = inv_freq
+
+    g = torch.Generator().manual_seed(51)
+    out = {}
+    for name, neox, T, H in (("gptj", False, 19, 16), ("neox", True, 7, 5)):
+        r = Rope()
+        r.head_size = r.rotary_dim = 64
+        r.base, r.max_position_embeddings, r.scaling_factor = 10000, 64, 4.0     # 256 cache rows (V3: 4096 x 40)
+        r.extrapolation_factor, r.beta_fast, r.beta_slow, r.device, r.is_neox_style = 1, 32, 1, "cpu", neox
+        r.mscale = float(ns["yarn_get_mscale"](4.0, 1.0) / ns["yarn_get_mscale"](4.0, 1.0) * 1.0)
+        r.cos_sin_cache = cache_fn(r)
+        pos = torch.randint(0, 256, (T,), generator=g)
+        q = torch.randn(T, H, 64, generator=g).to(torch.bfloat16)
+        k = torch.randn(T, 1, 64, generator=g).to(torch.bfloat16)
+        if neox:   # forward_native's neox branch assumes [batch, seq] positions (:826-830)
+            qo, ko = fwd(r, pos[None], q[None], k[None])
+            qo, ko = qo[0], ko[0]
+        else:
+            qo, ko = fwd(r, pos, q, k)
+        out.update({f"{name}_cache": r.cos_sin_cache.numpy(), f"{name}_pos": pos.numpy(), f"{name}_q": bf(q), f"{name}_k": bf(k),
+                    f"{name}_q_out": bf(qo.contiguous()), f"{name}_k_out": bf(ko.contiguous())})
+    np.savez_compressed(os.path.join(OUT, "rope_deepseek_yarn.npz"), **out)
+    print("rope", {k: v.shape for k, v in out.items() if k.endswith("_out")})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--only-rope" in sys.argv:
+        gen_rope()
+        sys.exit(0)
     if "--only-router" in sys.argv:
         gen_router()
         sys.exit(0)
@@ -264,4 +310,5 @@ if __name__ == "__main__":
     gen_gemm()
     gen_rmsnorm()
     gen_router()
+    gen_rope()
     print("golden written to", OUT)

@@ -157,3 +157,15 @@ def test_router_oracle_matches_reference_golden():
         c = router_case(g, name)
         w, ids = router_ref.biased_grouped_topk(c["logits"], c["bias"], c["G"], c["TG"], c["K"], c["scale"], c["on_out"], c["npad"])
         assert_router_rows_equal(w, ids, c["w"], c["ids"], c["npad"])
+
+
+def test_rope_oracle_bit_exact_vs_reference_golden():
+    """oracle.rope_ref.apply_rope ≡ DeepseekScalingRotaryEmbedding.forward_native (rotary_embedding.py:804-846) run from the
+    reference's own source with its YaRN fp32 cache: bf16 bits identical, GPT-J and NeoX styles."""
+    from oracle import rope_ref
+
+    g = load_golden("rope_deepseek_yarn.npz")
+    for name, neox in (("gptj", False), ("neox", True)):
+        for t in ("q", "k"):
+            out = rope_ref.apply_rope(g[name + "_pos"], g[f"{name}_{t}"], g[name + "_cache"], neox)
+            assert np.array_equal(out, g[f"{name}_{t}_out"]), (name, t)
