@@ -193,6 +193,15 @@ int fl_rope_inplace(const int64_t* positions, int64_t num_tokens, void* q, int64
                     int num_q_heads, void* k, int64_t k_stride_token, int64_t k_stride_head, int num_k_heads,
                     const float* cos_sin_cache, int64_t max_position, int rotary_dim, int is_neox, fl_stream_t stream);
 
+/* ---- K7: the work of copy_all_layer_kv_cache_tiled (srt/mem_cache/memory_pool.py:2055-2090) as
+ * MLATokenToKVPool.move_kv_cache launches it (:746-777): for every buffer b of the table, rows tgt_loc[i] <- src_loc[i]
+ * with the semantics of `buf[tgt] = buf[src]` (:756-763): all sources are read before any target is written (overlapping
+ * sets are safe).  data_ptrs / row_bytes: DEVICE tables [num_buffers] (base address, bytes per row; rows multiples of 4 B)
+ * like the reference's data_ptrs / data_strides (:330-343); max_row_bytes = host-known maximum of row_bytes; tgt/src int64
+ * DEVICE [num_locs], num_locs <= 8192; num_slots > 0: rows outside [0, num_slots) are skipped.  Bit-exact byte work. ---- */
+int fl_kv_move(const uint64_t* data_ptrs, const int64_t* row_bytes, int num_buffers, int64_t max_row_bytes,
+               const int64_t* tgt_loc, const int64_t* src_loc, int64_t num_locs, int64_t num_slots, fl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -293,8 +293,37 @@ def gen_rope():
     print("rope", {k: v.shape for k, v in out.items() if k.endswith("_out")})
 
 
+def gen_kv_move():
+    """move_kv_cache_native (mem_cache/memory_pool.py:2039-2052; the per_token_head MLA pool runs the same statement over its
+    three buffers per layer, :746-763) from the reference's own source: 2 layers x (k_lora u8 [S,512], k_scale f32 [S,1],
+    k_rope bf16 [S,64]) with OVERLAPPING source / target sets (a compaction: gather-all-then-scatter semantics)."""
+    import typing
+
+    ns = {"torch": torch, "List": typing.List}
+    move = _ref_import.load_function_from_source("/root/reference/python/sglang/srt/mem_cache/memory_pool.py",
+                                                 "move_kv_cache_native", ns)
+    g = torch.Generator().manual_seed(61)
+    S, L = 96, 2
+    lora = [torch.randint(0, 256, (S, 512), generator=g, dtype=torch.uint8) for _ in range(L)]
+    scale = [torch.rand(S, 1, generator=g) for _ in range(L)]
+    rope = [torch.randn(S, 64, generator=g).to(torch.bfloat16) for _ in range(L)]
+    src = torch.tensor([5, 6, 7, 8, 20, 21, 40, 41, 42, 43, 44, 90], dtype=torch.int64)
+    tgt = torch.tensor([4, 5, 6, 7, 8, 9, 38, 39, 40, 41, 42, 0], dtype=torch.int64)     # 5..8, 40..42 are read AND written
+    out = {"src": src.numpy(), "tgt": tgt.numpy()}
+    for l in range(L):
+        out.update({f"lora{l}": lora[l].numpy().copy(), f"scale{l}": scale[l].numpy().copy(), f"rope{l}": bf(rope[l]).copy()})
+    move(lora + scale, rope + [torch.zeros(S, 1) for _ in range(L)], tgt, src)
+    for l in range(L):
+        out.update({f"lora{l}_out": lora[l].numpy(), f"scale{l}_out": scale[l].numpy(), f"rope{l}_out": bf(rope[l])})
+    np.savez_compressed(os.path.join(OUT, "kv_move.npz"), **out)
+    print("kv_move", S, L, len(src))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--only-kv-move" in sys.argv:
+        gen_kv_move()
+        sys.exit(0)
     if "--only-rope" in sys.argv:
         gen_rope()
         sys.exit(0)
@@ -311,4 +340,5 @@ if __name__ == "__main__":
     gen_rmsnorm()
     gen_router()
     gen_rope()
+    gen_kv_move()
     print("golden written to", OUT)

@@ -338,3 +338,14 @@ def mla_decode_fp8_per_token_emulated(q_nope, q_scale, q_rope, k_lora, k_scale, 
         out[b][okq] = O[okq] / lq[okq][:, None]
         lse[b][ok] = (torch.log2(l[ok]) + M[ok] - 8.0) * math.log(2.0)
     return out.reshape(bs, s_q, H, dn), lse.reshape(bs, s_q, H).permute(0, 2, 1).contiguous()
+
+
+def move_kv_cache(buffers, tgt_loc, src_loc):
+    """`buf[tgt] = buf[src]` for every buffer (memory_pool.py:746-763 for the per_token_head MLA pool,
+    move_kv_cache_native :2039-2052): advanced indexing reads every source row before it writes any target row.
+    Pinned against tests/golden/kv_move.npz."""
+    if tgt_loc.numel() == 0:
+        return
+    t, s = tgt_loc.view(-1).long(), src_loc.view(-1).long()
+    for buf in buffers:
+        buf[t] = buf[s]

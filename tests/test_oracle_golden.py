@@ -169,3 +169,18 @@ def test_rope_oracle_bit_exact_vs_reference_golden():
         for t in ("q", "k"):
             out = rope_ref.apply_rope(g[name + "_pos"], g[f"{name}_{t}"], g[name + "_cache"], neox)
             assert np.array_equal(out, g[f"{name}_{t}_out"]), (name, t)
+
+
+def kv_move_buffers(g, suffix=""):
+    return [t for l in range(2) for t in (torch.from_numpy(g[f"lora{l}{suffix}"].copy()), torch.from_numpy(g[f"scale{l}{suffix}"].copy()),
+                                          bf16_from_u16(g[f"rope{l}{suffix}"]).clone())]
+
+
+def test_kv_move_oracle_bit_exact_vs_reference_golden():
+    """oracle.mla_ref.move_kv_cache ≡ the reference's move_kv_cache_native (memory_pool.py:2039-2052) on overlapping
+    source / target sets."""
+    g = load_golden("kv_move.npz")
+    bufs = kv_move_buffers(g)
+    mla_ref.move_kv_cache(bufs, torch.from_numpy(g["tgt"]), torch.from_numpy(g["src"]))
+    for got, want in zip(bufs, kv_move_buffers(g, "_out")):
+        assert torch.equal(got.view(torch.uint8), want.view(torch.uint8))
