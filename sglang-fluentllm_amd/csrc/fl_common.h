@@ -61,6 +61,43 @@ __device__ __forceinline__ uint32_t fl_cvt_pk_fp8(float a, float b) {
 __device__ __forceinline__ float fl_fp8_to_f32(uint8_t v) {
   return __builtin_amdgcn_cvt_f32_fp8((int)v, 0);
 }
+// Eight values divided by ONE divisor (a row's / group's quantisation scale) and rounded to fp8 e4m3.  hipcc expands every
+// `x / d` into the full correctly-rounded sequence (2 v_div_scale, v_rcp, 5 fma, v_div_fmas, v_div_fixup = 11 VALU ops, the
+// reciprocal included each time): the quantise kernels were VALU-bound on it (K4: 110 of 205 VALU ops per row).  The fast
+// branch is the SAME arithmetic (Newton-refined reciprocal, quotient, two residual corrections) with the divisor-only part
+// done once and without the exponent rescue of v_div_scale / v_div_fixup, taken only where that rescue is the identity:
+// d in [2^-60, 2^60] (uniform over the lanes that share d) and |x| <= 2^12 d.  Quotients so small that their fp32 value
+// would go denormal are far below half the smallest fp8 subnormal (2^-10) on both paths and round to the same signed
+// zero.  Bytes are bit-identical to cvt(x / d) (tests/: quantised bytes bit-exact vs the torch statement).
+// lo/hi: optional clamp of the quotient before the conversion (the 1x128 statement clamps to +-448).
+template <bool kClamp>
+__device__ __forceinline__ uint2 fl_div8_to_fp8(const float (&x)[8], const float d) {
+  float q[8];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(x[i]));
+  if (d >= 0x1p-60f && d <= 0x1p60f && amax <= d * 0x1p12f) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float r = fmaf(fmaf(-d, r0, 1.f), r0, r0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float t = x[i] * r;
+      t = fmaf(fmaf(-d, t, x[i]), r, t);
+      t = fmaf(fmaf(-d, t, x[i]), r, t);
+      q[i] = x[i] == 0.f ? x[i] : t;   // (-0 / d = -0: the corrections would turn it into +0)
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = x[i] / d;
+  }
+  if (kClamp) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = fminf(fmaxf(q[i], -FL_FP8_MAX), FL_FP8_MAX);
+  }
+  return make_uint2(fl_cvt_pk_fp8(q[0], q[1]) | (fl_cvt_pk_fp8(q[2], q[3]) << 16),
+                    fl_cvt_pk_fp8(q[4], q[5]) | (fl_cvt_pk_fp8(q[6], q[7]) << 16));
+}
+
 __device__ __forceinline__ float fl_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

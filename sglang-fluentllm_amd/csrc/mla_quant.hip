@@ -8,45 +8,62 @@
 //   K6 fl_mla_dequant_gather == flash_mla_fp8.dequantize_ckv_fused_indexed (memory_pool.py:821-831)
 //
 // HBM-bound byte work: one 64-lane wave per row, 16-B loads (8 bf16 of the 512-wide latent per lane, one
-// wave-wide shuffle reduction for amax), 8-B fp8 stores.  No LDS.  IEEE fp32 division (hipcc default
-// -fhip-fp32-correctly-rounded-divide-sqrt) so the bytes are bit-identical to the torch statement.
+// wave-wide shuffle reduction for amax), 8-B fp8 stores.  No LDS.  IEEE-exact fp32 division (fl_div8_to_fp8 in fl_common.h
+// for the 8 latent values, the compiler's correctly rounded `/` for the rope value) so the bytes are bit-identical to the
+// torch statement.
 #include "fl_common.h"
 
 namespace {
 
 constexpr int kWavesPerBlock = 4;
 
-// row: 576 bf16 = lanes 0..63 hold nope[8*lane .. 8*lane+7] and rope[lane].
-template <bool kScatter>
+// row: 576 bf16 = lanes 0..63 hold nope[8*lane .. 8*lane+7] and rope[lane].  A wave owns kRows neighbouring rows and issues
+// all of their loads before the first reduction (K4 at bs*H = 16384 rows: one wave per row is two rounds of 8 waves per
+// SIMD, each a full load -> reduce -> divide -> store latency chain).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool kScatter, int kRows>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void quant_rows_kernel(
     const uint16_t* __restrict__ src, int64_t n, const int32_t* __restrict__ indices, uint8_t* __restrict__ nope_out,
     float* __restrict__ scale_out, uint16_t* __restrict__ rope_out, int64_t num_slots) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (row >= n) return;
-  const uint16_t* p = src + row * 576;
-  const uint4 raw = *reinterpret_cast<const uint4*>(p + lane * 8);
-  const float rope = fl_bf16_to_f32(p[512 + lane]);
-  float v[8];
-  v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
-  v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
-  v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
-  v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
-  float amax = 0.f;
+  const int64_t row0 = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * kRows;
+  if (row0 >= n) return;
+  u32x4 raw[kRows];
+  uint16_t rope_raw[kRows];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));  // NaN inputs are the caller's problem, as in torch
-  amax = fl_wave_max(amax);
-  const float scale = fmaxf(amax, 1e-26f) / FL_FP8_MAX;
-  int64_t dst = row;
-  if (kScatter) {
-    dst = indices[row];
-    if (dst < 0 || dst >= num_slots) return;  // never write out of the pool
+  for (int r = 0; r < kRows; ++r) {
+    const int64_t row = row0 + r < n ? row0 + r : n - 1;   // (unconditional loads; the tail is not stored)
+    const uint16_t* p = src + row * 576;
+    raw[r] = *reinterpret_cast<const u32x4*>(p + lane * 8);
+    rope_raw[r] = p[512 + lane];
   }
-  uint32_t w0 = fl_cvt_pk_fp8(v[0] / scale, v[1] / scale) | (fl_cvt_pk_fp8(v[2] / scale, v[3] / scale) << 16);
-  uint32_t w1 = fl_cvt_pk_fp8(v[4] / scale, v[5] / scale) | (fl_cvt_pk_fp8(v[6] / scale, v[7] / scale) << 16);
-  *reinterpret_cast<uint2*>(nope_out + dst * 512 + lane * 8) = make_uint2(w0, w1);
-  rope_out[dst * 64 + lane] = fl_f32_to_bf16(rope / scale);
-  if (lane == 0) scale_out[dst] = scale;
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+    const int64_t row = row0 + r;
+    if (row >= n) break;
+    const float rope = fl_bf16_to_f32(rope_raw[r]);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(raw[r][i] << 16);
+      v[2 * i + 1] = __uint_as_float(raw[r][i] & 0xffff0000u);
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));  // NaN inputs are the caller's problem, as in torch
+    amax = fl_wave_max(amax);
+    const float scale = fmaxf(amax, 1e-26f) / FL_FP8_MAX;
+    int64_t dst = row;
+    if (kScatter) {
+      dst = indices[row];
+      if (dst < 0 || dst >= num_slots) continue;  // never write out of the pool
+    }
+    const uint2 w = fl_div8_to_fp8<false>(v, scale);   // 8 IEEE divisions by the row's scale (fl_common.h)
+    *reinterpret_cast<uint2*>(nope_out + dst * 512 + lane * 8) = w;
+    rope_out[dst * 64 + lane] = fl_f32_to_bf16(rope / scale);
+    if (lane == 0) scale_out[dst] = scale;
+  }
 }
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void dequant_gather_kernel(
@@ -80,9 +97,15 @@ extern "C" int fl_mla_quant_q(const void* q, int64_t rows, int d_nope, int d_rop
   FL_CHECK_ARG(d_nope == 512 && d_rope == 64, "fl_mla_quant_q: only d_nope=512,d_rope=64 (got %d,%d)", d_nope, d_rope);
   FL_CHECK_ARG(rows >= 0 && q && q_nope && q_scale && q_rope, "fl_mla_quant_q: null pointer");
   if (rows == 0) return FL_OK;
-  const int64_t blocks = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
-  quant_rows_kernel<false><<<dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream>>>(
-      (const uint16_t*)q, rows, nullptr, (uint8_t*)q_nope, q_scale, (uint16_t*)q_rope, rows);
+  if (rows >= 8192) {   // enough rows to fill the chip with 2 per wave
+    const int64_t blocks = (rows + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock);
+    quant_rows_kernel<false, 2><<<dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream>>>(
+        (const uint16_t*)q, rows, nullptr, (uint8_t*)q_nope, q_scale, (uint16_t*)q_rope, rows);
+  } else {
+    const int64_t blocks = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
+    quant_rows_kernel<false, 1><<<dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream>>>(
+        (const uint16_t*)q, rows, nullptr, (uint8_t*)q_nope, q_scale, (uint16_t*)q_rope, rows);
+  }
   FL_CHECK_LAUNCH("fl_mla_quant_q");
   return FL_OK;
 }
@@ -94,9 +117,15 @@ extern "C" int fl_mla_quant_store_k(const void* key, int64_t n, int d_nope, int 
   FL_CHECK_ARG(n >= 0 && key && indices && k_lora_cache && k_scale_cache && k_rope_cache,
                "fl_mla_quant_store_k: null pointer");
   if (n == 0) return FL_OK;
-  const int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
-  quant_rows_kernel<true><<<dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream>>>(
-      (const uint16_t*)key, n, indices, (uint8_t*)k_lora_cache, k_scale_cache, (uint16_t*)k_rope_cache, num_slots);
+  if (n >= 8192) {
+    const int64_t blocks = (n + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock);
+    quant_rows_kernel<true, 2><<<dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream>>>(
+        (const uint16_t*)key, n, indices, (uint8_t*)k_lora_cache, k_scale_cache, (uint16_t*)k_rope_cache, num_slots);
+  } else {
+    const int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+    quant_rows_kernel<true, 1><<<dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream>>>(
+        (const uint16_t*)key, n, indices, (uint8_t*)k_lora_cache, k_scale_cache, (uint16_t*)k_rope_cache, num_slots);
+  }
   FL_CHECK_LAUNCH("fl_mla_quant_store_k");
   return FL_OK;
 }

@@ -45,11 +45,7 @@ __device__ __forceinline__ uint2 quant_group(const float (&y)[8], float& s_out) 
   const float eps = fl_bf16_to_f32(fl_f32_to_bf16(1e-10f));
   const float s = fmaxf(amax, eps) / FL_FP8_MAX;
   s_out = s;
-  float q[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) q[i] = fminf(fmaxf(y[i] / s, -FL_FP8_MAX), FL_FP8_MAX);
-  return make_uint2(fl_cvt_pk_fp8(q[0], q[1]) | (fl_cvt_pk_fp8(q[2], q[3]) << 16),
-                    fl_cvt_pk_fp8(q[4], q[5]) | (fl_cvt_pk_fp8(q[6], q[7]) << 16));
+  return fl_div8_to_fp8<true>(y, s);   // y / s (IEEE), clamp to +-448, e4m3 (fl_common.h)
 }
 
 constexpr int kMaxChunks = 16;   // H <= 8192

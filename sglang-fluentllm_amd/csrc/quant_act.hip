@@ -27,12 +27,7 @@ __device__ __forceinline__ void unpack8(const uint4 raw, float (&v)[8]) {
 }
 
 __device__ __forceinline__ uint2 quant8(const float (&v)[8], float s) {
-  float q[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) q[i] = fminf(fmaxf(v[i] / s, -FL_FP8_MAX), FL_FP8_MAX);
-  const uint32_t w0 = fl_cvt_pk_fp8(q[0], q[1]) | (fl_cvt_pk_fp8(q[2], q[3]) << 16);
-  const uint32_t w1 = fl_cvt_pk_fp8(q[4], q[5]) | (fl_cvt_pk_fp8(q[6], q[7]) << 16);
-  return make_uint2(w0, w1);
+  return fl_div8_to_fp8<true>(v, s);   // v / s (IEEE), clamp to +-448, e4m3 (fl_common.h)
 }
 
 // one 16-lane group per (row, k-group); grid-stride over groups

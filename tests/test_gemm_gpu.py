@@ -36,6 +36,28 @@ def test_quant_1x128_bit_exact_vs_reference_golden():
     assert torch.equal(xq2.view(torch.uint8), xq.view(torch.uint8)) and torch.equal(xs2[:M].contiguous(), xs)
 
 
+def test_quant_1x128_divisions_bit_exact_on_adversarial_groups():
+    """Q1 divides by the group scale through fl_div8_to_fp8 (csrc/fl_common.h): 4 M elements with group magnitudes over 30
+    decades, signed and exact zeros, values tiny next to their group's maximum, all-zero groups (eps clamp) — bytes and scales
+    identical to the reference statement (test_block_fp8.py:15-40 restated in oracle.gemm_ref)."""
+    import flashinfer
+
+    g = torch.Generator().manual_seed(78)
+    M, K = 2048, 2048
+    x = torch.randn(M, K // 128, 128, generator=g) * torch.pow(10.0, torch.rand(M, K // 128, 1, generator=g) * 30 - 15)
+    x = x * torch.pow(2.0, -torch.randint(0, 40, (M, K // 128, 128), generator=g).float())
+    x[torch.rand(M, K // 128, 128, generator=g) < 0.05] = 0.0
+    x[torch.rand(M, K // 128, 128, generator=g) < 0.05] = -0.0
+    x[::53] = 0.0
+    x = x.view(M, K).to(torch.bfloat16)
+    rq, rs = gemm_ref.per_token_group_quant_fp8(x, 128)
+    xq = torch.empty(M, K, dtype=torch.float8_e4m3fn, device=DEV)
+    xs = torch.empty(M, K // 128, dtype=torch.float32, device=DEV)
+    flashinfer.sgl_per_token_group_quant_fp8(x.to(DEV), xq, xs, 128, 1e-10, -448.0, 448.0, False)
+    assert torch.equal(xq.cpu().view(torch.uint8), rq.view(torch.uint8))
+    assert torch.equal(xs.cpu().view(torch.int32), rs.view(torch.int32))
+
+
 def test_silu_and_mul_bit_exact_vs_reference_golden():
     import flashinfer
     from eps.executor import silu

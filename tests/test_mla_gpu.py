@@ -530,3 +530,29 @@ def test_bf16_decode_vs_reference_backend_golden(fm):
         ref = bf16_from_u16(g["o"]).view(-1, 1, H, 512)
         r = rel_mae(o.cpu(), ref)
         assert r < 8e-3, (name, r)   # both sides round P and the output to bf16 (different summation orders)
+
+
+def test_quant_divisions_bit_exact_on_adversarial_rows(fm):
+    """The quantise kernels divide by a shared scale through fl_div8_to_fp8 (csrc/fl_common.h) instead of the compiler's
+    per-element IEEE division: 2.4 M elements with row magnitudes over 36 decades, exact and signed zeros, values tiny
+    next to their row's maximum, rows of zeros — K5 / K4 bytes, scales and rope bits identical to the torch statement."""
+    g = torch.Generator().manual_seed(77)
+    n, slots = 4096, 4096
+    key = torch.randn(n, 1, 576, generator=g) * torch.pow(10.0, torch.rand(n, 1, 1, generator=g) * 36 - 18)
+    key = key * torch.pow(2.0, -torch.randint(0, 40, (n, 1, 576), generator=g).float())      # wide range inside a row
+    key[torch.rand(n, 1, 576, generator=g) < 0.05] = 0.0
+    key[torch.rand(n, 1, 576, generator=g) < 0.05] = -0.0
+    key[::97] = 0.0
+    key = key.to(torch.bfloat16)
+    loc = torch.randperm(slots, generator=g)[:n].to(torch.int32)
+    ref = [torch.zeros(slots, 1, 512, dtype=torch.uint8), torch.zeros(slots, 1, 1), torch.zeros(slots, 1, 64, dtype=torch.bfloat16)]
+    mla_ref.quantize_and_cache_k(key, ref[0], ref[1], ref[2], loc)
+    out = [torch.zeros_like(t, device=dev()) for t in ref]
+    fm.quantize_and_cache_k(key.to(dev()), out[0], out[1], out[2], loc.to(dev()), 512)
+    assert torch.equal(out[0].cpu(), ref[0]) and torch.equal(out[1].cpu(), ref[1])
+    assert torch.equal(out[2].cpu().view(torch.int16), ref[2].view(torch.int16))
+    q = key.view(32, 1, 128, 576).contiguous()
+    qn, qs, qr = fm.quantize_ckv_per_token_head(q.to(dev()), 512)
+    rn, rs, rr = mla_ref.quantize_ckv_per_token_head(q, 512)
+    assert torch.equal(qn.cpu().view(torch.uint8), rn.view(torch.uint8)) and torch.equal(qs.cpu(), rs)
+    assert torch.equal(qr.cpu().view(torch.int16), rr.view(torch.int16))
