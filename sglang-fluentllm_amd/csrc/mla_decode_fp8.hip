@@ -843,7 +843,8 @@ __global__ __launch_bounds__(64 * (2 * NRG + loader_waves(NRG)), 1) void mla_dec
 // ---- split-KV combine: out[req,row,:] = sum_s w_s * o_accum[slot_s,row,:], w_s = softmax_s(lse_s) ----
 __global__ __launch_bounds__(256) void mla_combine_kernel(const Params p, const int32_t* __restrict__ g_num_splits) {
   const int lane = threadIdx.x & 63;
-  const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // the wave index is uniform: say so, and the split counts / LSEs of the row come through the scalar cache
+  const long long gw = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (gw >= (long long)p.bs * p.rows) return;
   const int req = (int)(gw / p.rows), row = (int)(gw % p.rows);
   const int s0 = g_num_splits[req], ns = g_num_splits[req + 1] - s0;

@@ -89,8 +89,7 @@ __device__ __forceinline__ void combine_row(const Params& p, const int req, cons
   const float inv = den > 0.f ? 1.f / den : 0.f;
   uint32_t o[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    o[i] = (uint32_t)fl_f32_to_bf16(acc[2 * i] * inv) | ((uint32_t)fl_f32_to_bf16(acc[2 * i + 1] * inv) << 16);
+  for (int i = 0; i < 4; ++i) o[i] = fl_pack_bf16(acc[2 * i] * inv, acc[2 * i + 1] * inv);
   *reinterpret_cast<uint4*>(p.out + ((long long)req * p.rows + row) * kDN + lane * 8) = make_uint4(o[0], o[1], o[2], o[3]);
   if (lane == 0) {
     const int j = row / p.h_q, h = row - j * p.h_q;
