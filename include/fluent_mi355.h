@@ -202,6 +202,24 @@ int fl_rope_inplace(const int64_t* positions, int64_t num_tokens, void* q, int64
 int fl_kv_move(const uint64_t* data_ptrs, const int64_t* row_bytes, int num_buffers, int64_t max_row_bytes,
                const int64_t* tgt_loc, const int64_t* src_loc, int64_t num_locs, int64_t num_slots, fl_stream_t stream);
 
+/* ---- C8/C9: ep_scatter / ep_gather of the DeepExecutor (srt/layers/moe/executors/deep_ep_executor.py:271-332,
+ * 396-430; Triton kernels :173-268, :335-393): between the DeepEP dispatch and the contiguous grouped GEMM, and back.
+ * Strides in ELEMENTS of the tensor they belong to; topk / ids int32 or int64 (flag).  num_recv_tokens_per_expert: int32
+ * [E], each a multiple of 128; num_rows = rows of output_tensor / m_indices.  Order inside an expert's group: atomic
+ * cursors, unspecified as in the reference (:247).  expert_start_loc ends as start + count, like the reference's. ---- */
+int fl_ep_scatter(const void* recv_x /*fp8 [T, H]*/, int64_t x_stride, const float* recv_x_scale /*[T, H/128]*/,
+                  int64_t xs_stride, const void* recv_topk /*[T, K] local expert id or < 0*/, int topk_is_int64,
+                  int64_t topk_stride, int64_t num_tokens, int top_k, int hidden,
+                  const int32_t* num_recv_tokens_per_expert, int num_experts, int32_t* expert_start_loc /*[E] out*/,
+                  void* output_tensor /*fp8 [M, H]*/, int64_t out_stride, float* output_tensor_scale /*[M, H/128]*/,
+                  int64_t outs_stride, int32_t* m_indices /*[M]*/, int64_t num_rows, int32_t* output_index /*[T, K]*/,
+                  int64_t oi_stride, fl_stream_t stream);
+int fl_ep_gather(const void* input_tensor /*bf16 [M, H]*/, int64_t in_stride, int64_t num_rows,
+                 const void* recv_topk_ids /*[T, K]*/, int ids_is_int64, int64_t ids_stride,
+                 const float* recv_topk_weight /*[T, K]*/, int64_t w_stride, const int32_t* input_index /*[T, K]*/,
+                 int64_t idx_stride, int64_t num_tokens, int top_k, int hidden, void* output_tensor /*bf16 [T, H]*/,
+                 int64_t out_stride, fl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

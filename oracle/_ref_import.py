@@ -105,3 +105,51 @@ def load_function_from_source(path, func_name, namespace):
             exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), namespace)
             return namespace[func_name]
     raise KeyError(f"{func_name} not found in {path}")
+
+
+def load_triton_functions(path, names):
+    """exec() module-level functions of a reference file WITH their decorators (@triton.jit kernels and their Python
+    launchers) and run them on the CPU through Triton's interpreter (TRITON_INTERPRET=1 must be set before triton is
+    imported).  The stock interpreter's range()/tl.range() yield Python ints, on which the reference's kernels call
+    `.to(tl.int64)`: the namespace carries a range() and a `tl` proxy whose loop variables are interpreter tensors.
+    Programs of a grid run one after the other, so atomics hand out positions in program order."""
+    import ast
+    import builtins
+    import os
+
+    assert os.environ.get("TRITON_INTERPRET") == "1", "set TRITON_INTERPRET=1 before importing triton"
+    import torch
+    import triton
+    import triton.language as tl
+
+    def as_int(v):
+        return int(v.handle.data.item()) if hasattr(v, "handle") else int(v)
+
+    def py_range(*a):
+        try:
+            zero = tl.sum(tl.full([1], 0, tl.int32), 0)   # inside a kernel: an interpreter scalar
+        except Exception:
+            zero = None                                   # host code of a launcher
+        for v in builtins.range(*[as_int(v) for v in a]):
+            yield (zero + v) if zero is not None else v
+
+    class TL:
+        def __getattr__(self, k):
+            return getattr(tl, k)
+
+        @staticmethod
+        def range(a, b=None, step=None, **kw):
+            one = tl.full([1], 0, tl.int32)
+            for v in builtins.range(*[as_int(v) for v in (a, b, step) if v is not None]):
+                yield tl.sum(one, 0) + v
+
+    ns = {"torch": torch, "triton": triton, "tl": TL(), "_tl_module": tl, "range": py_range}
+    with open(path) as f:
+        tree = ast.parse(f.read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    missing = [n for n in names if n not in ns]
+    if missing:
+        raise KeyError(f"{missing} not found in {path}")
+    return ns

@@ -319,8 +319,46 @@ def gen_kv_move():
     print("kv_move", S, L, len(src))
 
 
+def gen_ep_scatter_gather():
+    """ep_scatter / ep_gather of the DeepExecutor (moe/executors/deep_ep_executor.py:173-430): the reference's own Triton
+    kernels run on the CPU by Triton's interpreter (run as: TRITON_INTERPRET=1 python oracle/gen_golden.py --only-ep).
+    fp8 rows + 1x128 scales scattered into 128-aligned expert groups, bf16 expert outputs gathered back with top-k weights."""
+    ns = _ref_import.load_triton_functions("/root/reference/python/sglang/srt/layers/moe/executors/deep_ep_executor.py",
+                                           ("_fwd_kernel_ep_scatter_1", "_fwd_kernel_ep_scatter_2", "ep_scatter",
+                                            "_fwd_kernel_ep_gather", "ep_gather"))
+    g = torch.Generator().manual_seed(71)
+    T, H, K, E = 45, 1024, 4, 4
+    x = torch.randint(0, 255, (T, H), generator=g, dtype=torch.uint8)
+    xs = torch.rand(T, H // 128, generator=g)
+    topk = torch.stack([torch.randperm(E + 4, generator=g)[:K] for _ in range(T)]).to(torch.int64)
+    topk[topk >= E] = -1                                    # experts of other ranks
+    topk[7] = -1
+    cnt = torch.bincount(topk[topk >= 0], minlength=E)
+    padded = ((cnt + 127) // 128 * 128).to(torch.int32)     # "token num of per expert is aligned to 128" (:281)
+    M = int(padded.sum())
+    start = torch.zeros(E, dtype=torch.int32)
+    out = torch.zeros(M, H, dtype=torch.uint8)
+    outs = torch.zeros(M, H // 128)
+    m_idx = torch.full((M,), -1, dtype=torch.int32)
+    oidx = torch.full((T, K), -1, dtype=torch.int32)
+    ns["ep_scatter"](x, xs, topk, padded, start, out, outs, m_idx, oidx)
+    y = torch.zeros(M, H, dtype=torch.bfloat16)            # (padding rows stay zero: the fixture compresses)
+    used = oidx[oidx >= 0].long()
+    y[used] = torch.randn(used.numel(), H, generator=g).to(torch.bfloat16)
+    w = torch.rand(T, K, generator=g)
+    gathered = torch.zeros(T, H, dtype=torch.float32)     # fp32 output: the interpreter's f32->bf16 cast truncates, GPUs round
+    ns["ep_gather"](y, topk, w, oidx, gathered)
+    np.savez_compressed(os.path.join(OUT, "ep_scatter_gather.npz"), x=x.numpy(), xs=xs.numpy(), topk=topk.numpy(),
+                        padded=padded.numpy(), start_after=start.numpy(), out=out.numpy(), outs=outs.numpy(),
+                        m_idx=m_idx.numpy(), oidx=oidx.numpy(), y=bf(y), w=w.numpy(), gathered=gathered.numpy())
+    print("ep_scatter_gather", T, H, K, E, M, start.tolist())
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--only-ep" in sys.argv:
+        gen_ep_scatter_gather()
+        sys.exit(0)
     if "--only-kv-move" in sys.argv:
         gen_kv_move()
         sys.exit(0)
@@ -341,4 +379,6 @@ if __name__ == "__main__":
     gen_router()
     gen_rope()
     gen_kv_move()
+    if os.environ.get("TRITON_INTERPRET") == "1":
+        gen_ep_scatter_gather()
     print("golden written to", OUT)

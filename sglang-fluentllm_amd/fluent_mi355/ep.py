@@ -33,6 +33,14 @@ class HipRowOps:
                   "fl_ep_combine"):
             getattr(lib, n).restype = i32
 
+    @staticmethod
+    def _stream_of(t):
+        from ._lib import stream_ptr
+
+        if not t.is_cuda:
+            raise RuntimeError("expected a CUDA/HIP tensor")
+        return stream_ptr(t.device)
+
     def route(self, indices, experts_per_rank, world, cap, send_slot, send_eid):
         self._check(self._lib.fl_ep_route(indices.data_ptr(), indices.numel(), experts_per_rank, world, cap,
                                           send_slot.data_ptr(), send_eid.data_ptr(), self._stream(indices.device)), "fl_ep_route")
@@ -116,3 +124,67 @@ class AllToAll:
         ret = self._a2a(back)
         self.row_ops.combine(ret, send_slot, weights.to(torch.float32).contiguous(), out_tokens, self.top_k)
         return out_tokens
+
+
+# ---- DeepExecutor's ep_scatter / ep_gather (python/sglang/srt/layers/moe/executors/deep_ep_executor.py:271-332,396-430) ----
+def _ep_sg_lib():
+    import ctypes
+
+    from ._lib import check, lib, stream_ptr
+
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    lib.fl_ep_scatter.argtypes = [vp, i64, vp, i64, vp, i32, i64, i64, i32, i32, vp, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, vp]
+    lib.fl_ep_gather.argtypes = [vp, i64, i64, vp, i32, i64, vp, i64, vp, i64, i64, i32, i32, vp, i64, vp]
+    lib.fl_ep_scatter.restype = lib.fl_ep_gather.restype = i32
+    return check, lib, stream_ptr
+
+
+def _ids(t, name):
+    if t.dtype not in (torch.int32, torch.int64) or t.stride(1) != 1:
+        raise RuntimeError(f"{name} must be int32 / int64 with a contiguous last dimension")
+    return int(t.dtype == torch.int64)
+
+
+@torch.no_grad()
+def ep_scatter(recv_x, recv_x_scale, recv_topk, num_recv_tokens_per_expert, expert_start_loc, output_tensor,
+               output_tensor_scale, m_indices, output_index):
+    """Same signature and effects as the reference's ep_scatter (deep_ep_executor.py:271-332): fills expert_start_loc,
+    m_indices, output_tensor(+scale) and output_index in place."""
+    check, lib, stream_ptr = _ep_sg_lib()
+    if recv_x.element_size() != 1 or recv_x.stride(1) != 1 or output_tensor.element_size() != 1 or output_tensor.stride(1) != 1:
+        raise RuntimeError("ep_scatter: recv_x / output_tensor must be fp8 rows with a contiguous last dimension")
+    if recv_x_scale.dtype != torch.float32 or output_tensor_scale.dtype != torch.float32 or recv_x_scale.stride(1) != 1 \
+            or output_tensor_scale.stride(1) != 1:
+        raise RuntimeError("ep_scatter: scales must be float32 with a contiguous last dimension")
+    if m_indices.shape[0] % 128:
+        raise RuntimeError("ep_scatter: m_indices must be a multiple of 128 rows (deep_ep_executor.py:290)")
+    for t, n in ((num_recv_tokens_per_expert, "num_recv_tokens_per_expert"), (expert_start_loc, "expert_start_loc"),
+                 (m_indices, "m_indices"), (output_index, "output_index")):
+        if t.dtype != torch.int32:
+            raise RuntimeError(f"ep_scatter: {n} must be int32")
+    T, K = recv_topk.shape
+    check(lib.fl_ep_scatter(recv_x.data_ptr(), recv_x.stride(0), recv_x_scale.data_ptr(), recv_x_scale.stride(0),
+                            recv_topk.data_ptr(), _ids(recv_topk, "recv_topk"), recv_topk.stride(0), T, K, recv_x.shape[1],
+                            num_recv_tokens_per_expert.data_ptr(), num_recv_tokens_per_expert.shape[0],
+                            expert_start_loc.data_ptr(), output_tensor.data_ptr(), output_tensor.stride(0),
+                            output_tensor_scale.data_ptr(), output_tensor_scale.stride(0), m_indices.data_ptr(),
+                            min(output_tensor.shape[0], m_indices.shape[0]), output_index.data_ptr(), output_index.stride(0),
+                            HipRowOps._stream_of(recv_x)), "fl_ep_scatter")
+
+
+@torch.no_grad()
+def ep_gather(input_tensor, recv_topk_ids, recv_topk_weight, input_index, output_tensor):
+    """Same signature and effect as the reference's ep_gather (deep_ep_executor.py:396-430): output_tensor[t] = sum over the
+    local experts of token t of weight * input_tensor[input_index[t, k]] (fp32 accumulate, bf16 out)."""
+    check, lib, stream_ptr = _ep_sg_lib()
+    if input_tensor.dtype != torch.bfloat16 or output_tensor.dtype != torch.bfloat16 or input_tensor.stride(1) != 1 \
+            or output_tensor.stride(1) != 1:
+        raise RuntimeError("ep_gather: input / output must be bf16 with a contiguous last dimension")
+    if recv_topk_weight.dtype != torch.float32 or input_index.dtype != torch.int32:
+        raise RuntimeError("ep_gather: weights must be float32 and input_index int32")
+    T, K = recv_topk_ids.shape
+    check(lib.fl_ep_gather(input_tensor.data_ptr(), input_tensor.stride(0), input_tensor.shape[0], recv_topk_ids.data_ptr(),
+                           _ids(recv_topk_ids, "recv_topk_ids"), recv_topk_ids.stride(0), recv_topk_weight.data_ptr(),
+                           recv_topk_weight.stride(0), input_index.data_ptr(), input_index.stride(0), output_tensor.shape[0], K,
+                           input_tensor.shape[1], output_tensor.data_ptr(), output_tensor.stride(0),
+                           HipRowOps._stream_of(input_tensor)), "fl_ep_gather")

@@ -184,3 +184,17 @@ def test_kv_move_oracle_bit_exact_vs_reference_golden():
     mla_ref.move_kv_cache(bufs, torch.from_numpy(g["tgt"]), torch.from_numpy(g["src"]))
     for got, want in zip(bufs, kv_move_buffers(g, "_out")):
         assert torch.equal(got.view(torch.uint8), want.view(torch.uint8))
+
+
+def test_ep_scatter_gather_oracle_exact_vs_reference_triton_golden():
+    """oracle.ep_ref ≡ the reference's Triton ep_scatter / ep_gather (deep_ep_executor.py:173-430) as run by Triton's CPU
+    interpreter (program order): every output of the scatter bit-exact, the gather's fp32 sums bit-exact."""
+    from oracle import ep_ref
+    from oracle.rope_ref import bf16_to_f32
+
+    g = load_golden("ep_scatter_gather.npz")
+    start, out, outs, m_idx, oidx = ep_ref.ep_scatter(g["x"], g["xs"], g["topk"], g["padded"])
+    assert np.array_equal(start, g["start_after"]) and np.array_equal(out, g["out"]) and np.array_equal(outs, g["outs"])
+    assert np.array_equal(m_idx, g["m_idx"]) and np.array_equal(oidx, g["oidx"])
+    got = ep_ref.ep_gather(bf16_to_f32(g["y"]), g["topk"], g["w"], g["oidx"])
+    assert np.array_equal(got, g["gathered"])
