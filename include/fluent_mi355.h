@@ -173,6 +173,13 @@ int fl_ep_send_rows(const void* x, int64_t num_tokens, const int32_t* send_slot 
 int fl_ep_combine(const void* ret_rows, int64_t num_ret_rows, const int32_t* send_slot, const float* weights,
                   int64_t num_tokens, int top_k, int hidden, void* out, fl_stream_t stream);
 
+/* A1-masked: silu_and_mul_masked_post_quant_fwd (srt/layers/moe/executors/deep_ep_executor.py:106-170, Triton kernel :31-104)
+ * between the two masked grouped GEMMs of the low-latency DeepEP path: x bf16 [G, rows_per_group, 2I] contiguous; only rows
+ * < masked_m[g] of group g are read / written: q_out fp8 [G, rows_per_group, I] contiguous, s_out f32 at
+ * g*s_stride_g + row*s_stride_m + kb*s_stride_k.  Arithmetic of A1 + Q1 (bit-exact vs their golden vectors). */
+int fl_silu_and_mul_masked(const void* x, int num_groups, int64_t rows_per_group, int I, const int32_t* masked_m, void* q_out,
+                           float* s_out, int64_t s_stride_g, int64_t s_stride_m, int64_t s_stride_k, fl_stream_t stream);
+
 /* ---- R1: flashinfer.moe_fused_gate as called by biased_grouped_topk_gpu (srt/layers/moe/topk.py:709-733);
  * semantics of its torch statement biased_grouped_topk_impl (topk.py:596-663), renormalize=True, no fused shared
  * experts.  logits f32 [T, E] (E = 64*2^k <= 1024), bias f32 [E]; num_expert_group a power of two <= 64;

@@ -62,16 +62,26 @@ __device__ __forceinline__ float silu_mul_bf16(float g, float u) {
   return fl_bf16_to_f32(fl_f32_to_bf16(sg * u));
 }
 
+// masked_m != nullptr: rows are [G groups][rows_per_group]; only the first masked_m[group] rows of a group are touched
+// (silu_and_mul_masked_post_quant_fwd, deep_ep_executor.py:106-170), scales at qs + group*s_stride_g + row*s_stride_m + kb*s_stride_k
 template <bool kQuant>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ x, long long M, int I,
                                                        uint16_t* __restrict__ out, uint8_t* __restrict__ q,
-                                                       float* __restrict__ qs, long long s_stride_m, long long s_stride_k) {
+                                                       float* __restrict__ qs, long long s_stride_m, long long s_stride_k,
+                                                       const int32_t* __restrict__ masked_m = nullptr,
+                                                       long long rows_per_group = 0, long long s_stride_g = 0) {
   const int kg = I / 128;
   const long long total = M * kg;
   const int sub = threadIdx.x & 15;
   for (long long g = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); g < total; g += (long long)gridDim.x * 16) {
     const long long m = g / kg;
     const int kb = (int)(g % kg);
+    long long s_off = m * s_stride_m;
+    if (masked_m != nullptr) {
+      const long long grp = m / rows_per_group, r = m - grp * rows_per_group;
+      if (r >= masked_m[grp]) continue;   // (uniform over the 16 lanes of a group)
+      s_off = grp * s_stride_g + r * s_stride_m;
+    }
     const uint16_t* pg = x + m * (2ll * I) + kb * 128 + sub * 8;
     float a[8], b[8], r[8];
     unpack8(*reinterpret_cast<const uint4*>(pg), a);
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restric
       amax = group16_max(amax);
       const float s = fmaxf(amax, fl_bf16_to_f32(fl_f32_to_bf16(1e-10f))) / FL_FP8_MAX;
       *reinterpret_cast<uint2*>(q + m * I + kb * 128 + sub * 8) = quant8(r, s);
-      if (sub == 0) qs[m * s_stride_m + kb * s_stride_k] = s;
+      if (sub == 0) qs[s_off + kb * s_stride_k] = s;
     }
   }
 }
@@ -130,5 +140,19 @@ extern "C" int fl_silu_and_mul(const void* x, int64_t M, int I, void* out_bf16, 
     silu_mul_kernel<false><<<grid, block, 0, (hipStream_t)stream>>>((const uint16_t*)x, M, I, (uint16_t*)out_bf16, nullptr,
                                                                     nullptr, 0, 0);
   FL_CHECK_LAUNCH("fl_silu_and_mul");
+  return FL_OK;
+}
+
+extern "C" int fl_silu_and_mul_masked(const void* x, int num_groups, int64_t rows_per_group, int I, const int32_t* masked_m,
+                                      void* q_out, float* s_out, int64_t s_stride_g, int64_t s_stride_m, int64_t s_stride_k,
+                                      fl_stream_t stream) {
+  FL_CHECK_ARG(x && masked_m && q_out && s_out, "fl_silu_and_mul_masked: null pointer");
+  FL_CHECK_ARG(num_groups >= 0 && rows_per_group >= 0 && I > 0 && I % 128 == 0,
+               "fl_silu_and_mul_masked: I=%d must be a multiple of 128", I);
+  const long long M = (long long)num_groups * rows_per_group;
+  if (M == 0) return FL_OK;
+  silu_mul_kernel<true><<<dim3(grid_for(M * (I / 128))), dim3(256), 0, (hipStream_t)stream>>>(
+      (const uint16_t*)x, M, I, nullptr, (uint8_t*)q_out, s_out, s_stride_m, s_stride_k, masked_m, rows_per_group, s_stride_g);
+  FL_CHECK_LAUNCH("fl_silu_and_mul_masked");
   return FL_OK;
 }

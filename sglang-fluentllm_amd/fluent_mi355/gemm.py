@@ -205,7 +205,9 @@ def silu_and_mul_fuse_block_quant(x, scale, out, enable_pdl=True, masked_m=None,
     out fp8 [.., I] = quant_1x128(silu(x[..,:I]) * x[..,I:]), scale f32 [.., I/128] (any strides) -> (out, scale)."""
     _req(x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(), "x must be contiguous bfloat16 on device")
     I = x.shape[-1] // 2
-    if x.dim() == 3:
+    if x.dim() == 3 and masked_m is not None:
+        silu_and_mul_masked_post_quant_fwd(x, out, scale, 128, masked_m)
+    elif x.dim() == 3:
         G, M, _ = x.shape
         for g in range(G):   # per-group scale strides may differ from a flat view; G is small (local experts)
             check(lib.fl_silu_and_mul(x[g].data_ptr(), M, I, None, out[g].data_ptr(), scale[g].data_ptr(),
@@ -215,3 +217,24 @@ def silu_and_mul_fuse_block_quant(x, scale, out, enable_pdl=True, masked_m=None,
         check(lib.fl_silu_and_mul(x.data_ptr(), M, I, None, out.data_ptr(), scale.data_ptr(), scale.stride(0),
                                   scale.stride(1), stream_ptr(x.device)), "fl_silu_and_mul")
     return out, scale
+
+
+def silu_and_mul_masked_post_quant_fwd(input, output, output_scale, quant_group_size, masked_m) -> None:
+    """Same signature and effect as the reference's Triton launcher (deep_ep_executor.py:106-170): input bf16
+    [G, M, 2I] contiguous, output fp8 [G, M, I] contiguous, output_scale f32 [G, M, I/128] (any strides), masked_m int32 [G];
+    rows >= masked_m[g] are neither read nor written.  One launch."""
+    _req(input.is_cuda and input.dtype == torch.bfloat16 and input.is_contiguous() and input.dim() == 3,
+         "input must be contiguous bfloat16 [G, M, 2I] on device")
+    _req(output.dtype == torch.float8_e4m3fn and output.is_contiguous(), "output must be contiguous float8_e4m3fn")
+    _req(int(quant_group_size) == 128, "quant_group_size must be 128")
+    _req(output_scale.dtype == torch.float32 and output_scale.dim() == 3, "output_scale must be float32 [G, M, I/128]")
+    G, M, two_i = input.shape
+    _req(masked_m.numel() == G, "masked_m must have one entry per group")
+    mm = masked_m if masked_m.dtype == torch.int32 else masked_m.to(torch.int32)
+    lib.fl_silu_and_mul_masked.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                           ctypes.c_void_p]
+    lib.fl_silu_and_mul_masked.restype = ctypes.c_int
+    check(lib.fl_silu_and_mul_masked(input.data_ptr(), G, M, two_i // 2, mm.contiguous().data_ptr(), output.data_ptr(),
+                                     output_scale.data_ptr(), output_scale.stride(0), output_scale.stride(1),
+                                     output_scale.stride(2), stream_ptr(input.device)), "fl_silu_and_mul_masked")

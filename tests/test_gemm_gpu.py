@@ -238,6 +238,34 @@ def test_gemm_graph_capture():
     assert torch.equal(out, eager)
 
 
+def test_silu_and_mul_masked_post_quant_vs_oracle():
+    """A1-masked (deep_ep_executor.py:106-170): [G, M, 2I] with masked_m rows per group in ONE launch; bytes and scales of the
+    live rows identical to the A1 + Q1 statements (oracle.gemm_ref), rows beyond masked_m never written (poisoned before);
+    also through flashinfer.activation.silu_and_mul_fuse_block_quant(masked_m=...) and with column-major scales."""
+    import flashinfer
+    from fluent_mi355.gemm import silu_and_mul_masked_post_quant_fwd
+
+    G, M, I = 5, 96, 384
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(G, M, 2 * I, generator=g) * 2).to(torch.bfloat16)
+    masked = torch.tensor([96, 0, 17, 1, 64], dtype=torch.int32)
+    act = gemm_ref.silu_and_mul(x.view(G * M, 2 * I)).view(G, M, I)
+    rq, rs = gemm_ref.per_token_group_quant_fp8(act.contiguous(), 128)
+    for col_major in (False, True):
+        q = torch.full((G, M, I), 0x7F, dtype=torch.uint8, device=DEV).view(torch.float8_e4m3fn)
+        sc = torch.full((G, I // 128, M) if col_major else (G, M, I // 128), -7.0, device=DEV)
+        sc = sc.permute(0, 2, 1) if col_major else sc
+        if col_major:
+            flashinfer.activation.silu_and_mul_fuse_block_quant(x.to(DEV), sc, q, True, masked_m=masked.to(DEV))
+        else:
+            silu_and_mul_masked_post_quant_fwd(x.to(DEV), q, sc, 128, masked.to(DEV))
+        qc, scc = q.view(torch.uint8).cpu(), sc.cpu()
+        for gi in range(G):
+            m = int(masked[gi])
+            assert torch.equal(qc[gi, :m], rq.view(torch.uint8)[gi, :m]) and torch.equal(scc[gi, :m], rs[gi, :m])
+            assert bool((qc[gi, m:] == 0x7F).all()) and bool((scc[gi, m:] == -7.0).all())
+
+
 def test_ep_all_to_all_single_rank_hip_row_ops():
     """C1/C2 device kernels (route / sort / gather / scatter / combine) on one GPU (world 1: the exchange is a copy);
     the multi-rank host logic is covered on CPU with gloo in test_ep_gloo_cpu.py."""
