@@ -63,28 +63,45 @@ __device__ __forceinline__ void combine_row(const Params& p, const int req, cons
   }
   float den = 0.f, denx = 0.f;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // splits in chunks of kChunk: the partial rows of a chunk are loaded before the first is used (a run-time split count
+  // up to 64 would otherwise be that many dependent round trips per row)
+  constexpr int kChunk = NS > 0 ? NS : 8;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  for (int c0 = 0; c0 < ns; c0 += kChunk) {
+    u32x4 ua[kChunk], ub[kChunk];
+    float ls[kChunk], lx[kChunk];
 #pragma unroll
-  for (int s = 0; s < ns; ++s) {
-    const float ls = p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 0];
-    const float lx = p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 1];
-    const float wgt = (mx == -INFINITY) ? 0.f : __expf(ls - mx);
-    den += wgt;
-    denx += (mxx == -INFINITY) ? 0.f : __expf(lx - mxx);
-    float4 a, b;
-    if (p.partial_bf16) {
-      const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.o_accum) +
-                                                       ((long long)(s0 + s) * p.rows + row) * kDN + lane * 8);
-      a = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                      __uint_as_float(u.y & 0xffff0000u));
-      b = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
-                      __uint_as_float(u.w & 0xffff0000u));
-    } else {
-      const float* src = p.o_accum + ((long long)(s0 + s) * p.rows + row) * kDN + lane * 8;
-      a = *reinterpret_cast<const float4*>(src);
-      b = *reinterpret_cast<const float4*>(src + 4);
+    for (int j = 0; j < kChunk; ++j) {
+      const int s = c0 + j < ns ? c0 + j : ns - 1;   // (unconditional loads; the tail is weighted 0 below)
+      const long long base = (long long)(s0 + s) * p.rows + row;
+      ls[j] = p.lse_accum[base * 2 + 0];
+      lx[j] = p.lse_accum[base * 2 + 1];
+      if (p.partial_bf16) {
+        ua[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p.o_accum) + base * kDN + lane * 8);
+      } else {
+        ua[j] = *reinterpret_cast<const u32x4*>(p.o_accum + base * kDN + lane * 8);
+        ub[j] = *reinterpret_cast<const u32x4*>(p.o_accum + base * kDN + lane * 8 + 4);
+      }
     }
-    acc[0] += wgt * a.x; acc[1] += wgt * a.y; acc[2] += wgt * a.z; acc[3] += wgt * a.w;
-    acc[4] += wgt * b.x; acc[5] += wgt * b.y; acc[6] += wgt * b.z; acc[7] += wgt * b.w;
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+      const bool live = c0 + j < ns;
+      const float wgt = (!live || mx == -INFINITY) ? 0.f : __expf(ls[j] - mx);
+      den += wgt;
+      denx += (!live || mxx == -INFINITY) ? 0.f : __expf(lx[j] - mxx);
+      float f[8];
+      if (p.partial_bf16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(ua[j][q] << 16); f[2 * q + 1] = __uint_as_float(ua[j][q] & 0xffff0000u); }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { f[q] = __uint_as_float(ua[j][q]); f[4 + q] = __uint_as_float(ub[j][q]); }
+      }
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += wgt * f[i];
+      }
+    }
   }
   const float inv = den > 0.f ? 1.f / den : 0.f;
   uint32_t o[4];

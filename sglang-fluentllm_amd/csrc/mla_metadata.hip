@@ -15,6 +15,7 @@
 
 namespace {
 constexpr int kFixedOverhead = 2;
+constexpr int kMaxSplits = 64;   // parts per request (oracle/mla_ref.py: MAX_SPLITS)
 constexpr int kMaxBs = 8192;   // tile counts are staged in LDS
 
 // Both walks are FLAT loops — one event (a request consumed, or a part closed) per iteration, selects instead of nested
@@ -50,18 +51,27 @@ __global__ __launch_bounds__(64) void mla_metadata_kernel(const int32_t* __restr
   __shared__ int ps_req[kMaxParts + 2], ps_tile[kMaxParts + 2], ps_split[kMaxParts + 2];   // (+ end, + dummy)
   __shared__ int s_last;
   const int lane = threadIdx.x;
-  int total = 0;
+  int total = 0, nt_max = 0;
   for (int b = lane; b < bs; b += 64) {
     const int L = seqlens[b];
     const int nt = L > 0 ? (L + FL_MLA_PAGE - 1) / FL_MLA_PAGE : 0;
     nt_of[b] = nt;
     total += nt + kFixedOverhead;
+    nt_max = nt > nt_max ? nt : nt_max;
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+  for (int o = 32; o > 0; o >>= 1) {
+    total += __shfl_xor(total, o);
+    const int other = __shfl_xor(nt_max, o);
+    nt_max = other > nt_max ? other : nt_max;
+  }
   __syncthreads();
   int p_min = (total + num_parts - 1) / num_parts;
   if (p_min < 1 + kFixedOverhead) p_min = 1 + kFixedOverhead;
+  // no request in more than kMaxSplits parts: a part of one or two pages is all prologue / epilogue and the merge of a row
+  // grows with its split count
+  const int p_cap = (nt_max + kMaxSplits - 1) / kMaxSplits + kFixedOverhead;
+  if (p_min < p_cap) p_min = p_cap;
   // lane l tests capacity p_min + l; the fixed formula's capacity (p_min + FIXED_OVERHEAD) is the fallback
   const bool ok = parts_needed(nt_of, bs, p_min + lane, num_parts) <= num_parts;
   const unsigned long long okmask = __ballot(ok);
