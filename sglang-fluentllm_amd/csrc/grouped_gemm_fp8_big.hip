@@ -116,6 +116,24 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big_kernel(const Gemm
     rb[s] = li * BK + ((c ^ ((li >> 1) & 7)) << 4);
   }
 
+  // acc += part * sc: 8 packed fp32 FMAs (v_pk_fma_f32) per tile instead of 16 scalar ones with FL_GEMM_PKFMA
+  auto promote = [](v16f& a, const v16f& pt, const float sc) {
+#ifdef FL_GEMM_PKFMA
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f s2 = {sc, sc};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const v2f x = {pt[2 * r], pt[2 * r + 1]};
+      v2f y = {a[2 * r], a[2 * r + 1]};
+      y = __builtin_elementwise_fma(x, s2, y);
+      a[2 * r] = y[0];
+      a[2 * r + 1] = y[1];
+    }
+#else
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = fmaf(pt[r], sc, a[r]);
+#endif
+  };
   v16f acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -206,8 +224,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big_kernel(const Gemm
       if (t > 0) {
         const int tp = t - 1, jp = tp >> 1, ip = tp & 1;
         asm volatile("s_nop 3" : "+v"(part[tp & 1]));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ip][jp][r] = fmaf(part[tp & 1][r], sc_prev, acc[ip][jp][r]);
+        promote(acc[ip][jp], part[tp & 1], sc_prev);
         asm volatile("" : "+v"(acc[ip][jp]));   // pin: the promotion happens HERE (else it is sunk to the end of the k block
                                               // and every partial tile stays live: spills)
       }
@@ -217,8 +234,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big_kernel(const Gemm
     // the last tile: a 16-pass XDL write needs 18 wait states (of 4 clocks: probes/probe_snop.hip measures s_nop 7 = 36
     // clocks) before a VALU read; its pair issued before the last refill piece and the promotion of tile 6 (> 250 clocks)
     asm volatile("s_nop 7\n\ts_nop 7" : "+v"(part[1]));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[1][3][r] = fmaf(part[1][r], sc_prev, acc[1][3][r]);
+    promote(acc[1][3], part[1], sc_prev);
     asm volatile("" : "+v"(acc[1][3]));
   }
 
