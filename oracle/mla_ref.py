@@ -206,7 +206,7 @@ META_W = 8
 FIXED_OVERHEAD_TILES = 2
 
 
-MAX_SPLITS = 64
+MIN_SPLIT_CAP, PAGES_PER_SPLIT = 32, 8
 
 
 def _parts_needed(ntiles, capacity, limit):
@@ -242,9 +242,11 @@ def get_mla_metadata(cache_seqlens, num_parts: int, page_size: int = PAGE_SIZE):
     ntiles = [((L + page_size - 1) // page_size) if L > 0 else 0 for L in seqlens]
     total = sum(n + FIXED_OVERHEAD_TILES for n in ntiles)
     p_min = max((total + num_parts - 1) // num_parts, 1 + FIXED_OVERHEAD_TILES)
-    # no request in more than MAX_SPLITS parts: a part of one or two pages is all prologue / epilogue, and the merge of a row
-    # grows with its split count (bs=1, seq=16384 on 256 parts: 157 us per layer before)
-    p_min = max(p_min, (max(ntiles, default=0) + MAX_SPLITS - 1) // MAX_SPLITS + FIXED_OVERHEAD_TILES)
+    # no request in more than max(32, pages/8) parts: a part of one or two pages is all prologue / epilogue, and the merge of
+    # a row grows with its split count (bs=1, seq=16384 on 256 parts: 157 us per layer before)
+    nt_max = max(ntiles, default=0)
+    split_cap = max(MIN_SPLIT_CAP, nt_max // PAGES_PER_SPLIT)
+    p_min = max(p_min, (nt_max + split_cap - 1) // split_cap + FIXED_OVERHEAD_TILES)
     payload = p_min + FIXED_OVERHEAD_TILES
     for cand in range(p_min, p_min + 64):
         if _parts_needed(ntiles, cand, num_parts) <= num_parts:

@@ -15,7 +15,7 @@
 
 namespace {
 constexpr int kFixedOverhead = 2;
-constexpr int kMaxSplits = 64;   // parts per request (oracle/mla_ref.py: MAX_SPLITS)
+constexpr int kMinSplitCap = 32, kPagesPerSplit = 8;   // parts per request <= max(32, pages / 8) (oracle/mla_ref.py)
 constexpr int kMaxBs = 8192;   // tile counts are staged in LDS
 
 // Both walks are FLAT loops — one event (a request consumed, or a part closed) per iteration, selects instead of nested
@@ -68,9 +68,10 @@ __global__ __launch_bounds__(64) void mla_metadata_kernel(const int32_t* __restr
   __syncthreads();
   int p_min = (total + num_parts - 1) / num_parts;
   if (p_min < 1 + kFixedOverhead) p_min = 1 + kFixedOverhead;
-  // no request in more than kMaxSplits parts: a part of one or two pages is all prologue / epilogue and the merge of a row
-  // grows with its split count
-  const int p_cap = (nt_max + kMaxSplits - 1) / kMaxSplits + kFixedOverhead;
+  // no request in more than max(32, pages/8) parts: a part of one or two pages is all prologue / epilogue and the merge of
+  // a row grows with its split count (tools/bench_one_batch.py at bs = 1, 2: 32 parts are best up to 16 K tokens, 128 at 64 K)
+  const int split_cap = nt_max / kPagesPerSplit > kMinSplitCap ? nt_max / kPagesPerSplit : kMinSplitCap;
+  const int p_cap = (nt_max + split_cap - 1) / split_cap + kFixedOverhead;
   if (p_min < p_cap) p_min = p_cap;
   // lane l tests capacity p_min + l; the fixed formula's capacity (p_min + FIXED_OVERHEAD) is the fallback
   const bool ok = parts_needed(nt_of, bs, p_min + lane, num_parts) <= num_parts;

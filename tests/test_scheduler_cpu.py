@@ -43,4 +43,6 @@ def test_random_ragged():
 
 def test_small_batch_splits_long_sequence():
     meta, ns = _coverage([16384], 128)
-    assert ns[1] == 64  # one long request is spread over many CUs, up to MAX_SPLITS parts (4 pages each here)
+    assert ns[1] == 32  # one long request is spread over many CUs: max(32, pages/8) parts (256 pages -> 32 x 8 here)
+    meta, ns = _coverage([65536], 256)
+    assert ns[1] == 128
