@@ -253,7 +253,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8_e4m3 (KV, Q, P) x fp8 -> f32 acc; bf16 rope; bf16 out", "data": "synthetic",
             "config": {"workload": "DeepSeek-V3 MLA decode, per-token fp8 KV, bs=128/GPU seq=4096 H=128 (TP=1), page=64, "
-                                   "pages randomly permuted, 61 layers x (K5 store + K4 quant-q + K1 decode) per step",
+                                   "pages randomly permuted, K3 metadata once + 61 layers x (K5 store + K4 quant-q + K1 decode) per step",
                        "bs_per_gpu": BS, "seq_len": SEQ, "heads": H, "layers_per_step": layers,
                        "parallelism": f"dp{world} (DP-attention, no data-path collective)", "hipgraph": graph is not None},
             "roofline": roof, "cpu_baseline": cpu}))
