@@ -41,8 +41,9 @@ __global__ __launch_bounds__(256) void quant_1x128_kernel(const uint16_t* __rest
   // .to(float32)), i.e. with eps rounded to the input dtype; only rows with amax < 1e-10 can tell the difference.
   eps = fl_bf16_to_f32(fl_f32_to_bf16(eps));
   for (long long g = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); g < total; g += (long long)gridDim.x * 16) {
-    const long long m = g / kg;
-    const int kb = (int)(g % kg);
+    // (32-bit division when it fits: the 64-bit one is ~80 VALU ops in a kernel that is one load -> reduce -> store chain)
+    const long long m = total < (1ll << 31) ? (long long)((unsigned)g / (unsigned)kg) : g / kg;
+    const int kb = (int)(g - m * kg);
     const uint16_t* p = x + m * K + kb * 128 + sub * 8;
     float v[8];
     unpack8(*reinterpret_cast<const uint4*>(p), v);
@@ -74,11 +75,12 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restric
   const long long total = M * kg;
   const int sub = threadIdx.x & 15;
   for (long long g = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); g < total; g += (long long)gridDim.x * 16) {
-    const long long m = g / kg;
-    const int kb = (int)(g % kg);
+    const long long m = total < (1ll << 31) ? (long long)((unsigned)g / (unsigned)kg) : g / kg;
+    const int kb = (int)(g - m * kg);
     long long s_off = m * s_stride_m;
     if (masked_m != nullptr) {
-      const long long grp = m / rows_per_group, r = m - grp * rows_per_group;
+      const long long grp = total < (1ll << 31) ? (long long)((unsigned)m / (unsigned)rows_per_group) : m / rows_per_group;
+      const long long r = m - grp * rows_per_group;
       if (r >= masked_m[grp]) continue;   // (uniform over the 16 lanes of a group)
       s_off = grp * s_stride_g + r * s_stride_m;
     }
