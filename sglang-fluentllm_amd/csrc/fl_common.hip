@@ -24,6 +24,15 @@ bool fl_mla_use_x() {
   }();
   return on;
 }
+bool fl_mla_use_y() {
+  // role-specialised 64-row MLA decode mapping (mla_decode_fp8_y.hip) for per-token-FP8 KV and s_q*H > 32: default on;
+  // FLUENT_MLA_Y=0 falls back to the mappings above.  Read once: the scheduler's part count depends on it.
+  static const bool on = [] {
+    const char* e = getenv("FLUENT_MLA_Y");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
+}
 int fl_mla_x_rows_per_wg() {
   // query rows one workgroup of mla_decode_fp8_x.hip owns when a request has more than 64: 128 (one workgroup streams a
   // KV part once for all rows; long requests are split along KV) or, with FLUENT_MLA_X_ROWS=64, 64 (row groups of one

@@ -842,29 +842,35 @@ __global__ __launch_bounds__(64 * (2 * NRG + loader_waves(NRG)), 1) void mla_dec
 
 // ---- split-KV combine: out[req,row,:] = sum_s w_s * o_accum[slot_s,row,:], w_s = softmax_s(lse_s) ----
 __global__ __launch_bounds__(256) void mla_combine_kernel(const Params p, const int32_t* __restrict__ g_num_splits) {
+  // nothing is split (every request has exactly one part): one scalar load per workgroup and out
+  if (g_num_splits[p.bs] == p.bs) return;
   const int lane = threadIdx.x & 63;
   // the wave index is uniform: say so, and the split counts / LSEs of the row come through the scalar cache
-  const long long gw = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (gw >= (long long)p.bs * p.rows) return;
-  const int req = (int)(gw / p.rows), row = (int)(gw % p.rows);
-  const int s0 = g_num_splits[req], ns = g_num_splits[req + 1] - s0;
-  if (ns <= 1) return;
-  if (ns == 2) combine_row<2>(p, req, row, s0, ns, lane);   // the uniform full batch: two parts per request
-  else if (ns == 3) combine_row<3>(p, req, row, s0, ns, lane);
-  else if (ns == 4) combine_row<4>(p, req, row, s0, ns, lane);
-  else combine_row<0>(p, req, row, s0, ns, lane);
+  const long long total = (long long)p.bs * p.rows;
+  for (long long gw = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); gw < total;
+       gw += (long long)gridDim.x * 4) {
+    const int req = (int)(gw / p.rows), row = (int)(gw % p.rows);
+    const int s0 = g_num_splits[req], ns = g_num_splits[req + 1] - s0;
+    if (ns <= 1) continue;
+    if (ns == 2) combine_row<2>(p, req, row, s0, ns, lane);   // the uniform full batch: two parts per request
+    else if (ns == 3) combine_row<3>(p, req, row, s0, ns, lane);
+    else if (ns == 4) combine_row<4>(p, req, row, s0, ns, lane);
+    else combine_row<0>(p, req, row, s0, ns, lane);
+  }
 }
 
 }  // namespace
 
 int fl_mla_launch_combine(const Params& p, const int32_t* num_splits, hipStream_t stream) {
   const long long waves = (long long)p.bs * p.rows;
-  mla_combine_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(p, num_splits);
+  const long long blocks = (waves + 3) / 4;   // one wave per (request, row); grid-stride beyond 2048 workgroups
+  mla_combine_kernel<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream>>>(p, num_splits);
   FL_CHECK_LAUNCH("mla_combine_kernel");
   return FL_OK;
 }
 
 int fl_mla_decode_fp8_x_impl(const FlMlaDecodeArgs* a, const Params& p, hipStream_t stream);   // mla_decode_fp8_x.hip
+int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p, hipStream_t stream);   // mla_decode_fp8_y.hip
 
 int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   const bool per_token = a->kv_format == FL_KV_FP8_PER_TOKEN;
@@ -891,6 +897,8 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   // At most 32 rows stay here: ONE slot-pipelined compute wave would carry all 40 MFMAs of a page on one SIMD (H=16:
   // 85.8 us) where this file's two half-waves + two loaders take 78.3.  FLUENT_MLA_X=0: this file for every shape.
   // fl_mla_num_parts sizes the scheduler's part count with the same rule.
+  // Role-specialised 64-row workgroups (mla_decode_fp8_y.hip): per-token FP8, more than 32 query rows per request.
+  if (per_token && fl_mla_use_y() && p.rows > 32) return fl_mla_decode_fp8_y_impl(a, p, stream);
   static const bool x_small = [] {
     const char* e = getenv("FLUENT_MLA_X_SMALL");
     return !(e != nullptr && e[0] == '0');

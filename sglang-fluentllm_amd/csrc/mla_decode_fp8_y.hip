@@ -1,0 +1,721 @@
+// K1 for more than 32 query rows per request — paged MLA decode over the per-token-FP8 latent KV cache with
+// ROLE-SPECIALISED waves, gfx950 (MI355X) only.  Same math, data formats and call sites as mla_decode_fp8.hip
+// (flash_mla_fp8.flash_mla_ckv_fp8_per_token, flashmla_backend.py:208-222 decode / :127-142 verify).
+//
+// Why a third mapping.  One wave per SIMD issues in order: in mla_decode_fp8_x.hip (128 rows, 4 waves x 512 registers) a
+// page costs ~4400 issue cycles against 2304 cycles of matrix pipe, and the whole batch had to be split along KV (bf16
+// partials + a merge kernel: 31 of 118 us at bs=128, seq=4096, H=128).  Here a workgroup owns 64 query rows and runs
+// EIGHT waves, two per SIMD, at <= 256 registers each:
+//   * QK waves q(rt, W) (wave ids 0..3): S^T[32 tok x 32 rows] = K[32W..] . Q_rt^T (4 bf16 rope + 8 MX-fp8 MFMAs), the
+//     online softmax of that block on y = s*log2e + log2 k_scale[t] with an integer reference per (row, block), the
+//     e4m3 weights P' = 2^(y - m + 8) and both normalisers; P' (16 B per lane) and the reference go to LDS.
+//   * PV waves v(rt, Wd) (wave ids 4..7, on the SAME SIMD as q(rt', W') with the same low id bits): one step later,
+//     O^T[256 dims of half Wd x 32 rows] += V^T . P^T (8 MX-fp8 MFMAs, K = 64 tokens; the two blocks' references are
+//     reconciled by the E8M0 block scales), V^T by ds_read_b64_tr_b8 from the same LDS bytes the QK waves read as K;
+//     they also issue every LDS-DMA refill (8 pieces of 1 KiB per wave and page) and zero the tail of the last page.
+//   so the softmax VALU work of one wave runs beside the other wave's MFMAs on each SIMD, nobody holds both Q (80
+//   registers) and O (128), and a 128-head request is two neighbouring workgroups of one XCD that walk ALL its pages
+//   (the second reader of a page hits the XCD's L2): no KV split, no partials and no merge kernel for a full batch.
+//   * LDS: 4-slot ring of 32 KiB latent pages (page i-1 read as V^T, page i as K, pages i+1, i+2 landing) + double-
+//     buffered P' / references + wave-private scale scratch.  Rope (bf16, 4 KiB per QK wave and page) and the raw
+//     k_scale go global -> registers in the QK waves, two pages ahead (a rope ring does not fit beside the P buffers).
+//   * ONE s_barrier per page step: step i = QK(i) + softmax(i) || PV(i-1) + refill of page i+2.
+// Split requests (fewer requests than parts) write normalised bf16 partial rows + {weight-LSE, exact-LSE} exactly like
+// mla_decode_fp8_x.hip and are merged by mla_combine_kernel.
+#include "mla_decode_shared.h"
+
+using namespace fl_mla;
+
+namespace {
+
+constexpr int kOffRing = 0;                                        // 4 x 32 KiB
+constexpr int kPbufPerParity = 2 * 2 * 64 * 16;                    // [rt 2][W 2][64 lanes][16 B]
+constexpr int kOffPbuf = kOffRing + kRingSlots * kSlotBytes;       // [parity 2]
+constexpr int kRefPerParity = 2 * 2 * 32 * 4;                      // [rt 2][W 2][32 rows] f32
+constexpr int kOffRef = kOffPbuf + 2 * kPbufPerParity;             // [parity 2]
+constexpr int kScratchPerWave = 3 * 32 * 4;                        // {ks, log2 ks, 1/ks} x 32 tokens
+constexpr int kOffScratch = kOffRef + 2 * kRefPerParity;           // [QK wave 4]
+constexpr int kOffLm = kOffScratch + 4 * kScratchPerWave;          // [rt 2][W 2][3][32] f32: l, lq, m per row
+constexpr int kOffFlag = kOffLm + 2 * 2 * 3 * 32 * 4;              // 4 ints: redo votes of the PV waves
+constexpr int kLdsBytes = kOffFlag + 16;
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+constexpr int kStgStride = 128 + 4;                                // epilogue staging: floats per row (in the ring)
+static_assert(4 * 32 * kStgStride * 4 <= kRingSlots * kSlotBytes, "epilogue staging fits the ring");
+
+constexpr int kPiecesPerWave = kDmaNopePerTile / 4;                // 8 LDS-DMA pieces of 1 KiB per PV wave and page
+
+#ifndef FL_Y_NOWAIT
+#define FL_Y_NOWAIT 0
+#endif
+#ifndef FL_Y_MID_BARRIER
+#define FL_Y_MID_BARRIER 0   // experiment (measured slower: 134.7 vs 127-133 us): second barrier per step between the QK
+                             // waves' MFMA chain and the PV waves' MFMAs
+#endif
+#ifdef FL_MLA_TIMING
+__device__ int* g_dbg_y = nullptr;   // debug builds only: set by fl_mla_debug_set_buffer_y
+#define FL_T(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); tacc[i] += t__ - tlast; tlast = t__; } while (0)
+#define FL_T_PARAMS , unsigned long long (&tacc)[12], unsigned long long& tlast
+#define FL_T_ARGS , tacc, tlast
+#else
+#define FL_T(i) do { } while (0)
+#define FL_T_PARAMS
+#define FL_T_ARGS
+#endif
+
+// Rope A operand (4 bf16 k-steps) and raw k_scale of one page for one QK wave, held in registers two pages ahead.
+struct RopeRegs {
+  uint4 ra[4];
+  float ks;
+};
+
+struct QkLane {
+  int kb0;   // K operand: byte offset inside a slot for k-step 0, first 16 B (second: ^16); k-step s: ^ ((s&3) << 6), + (s>>2)*256
+};
+struct PvLane {
+  int vb0;          // V^T tr8 source of tile jb = 0 (tile jb: ^ ((jb&3) << 4) ^ ((jb>>2) << 7)); + u immediates; + Wd*256
+  unsigned dn_row;  // latent DMA: byte offset of this lane's token row of piece 0 of this wave (piece k: + k * 1024)
+  unsigned dn_x;    // ... and its swizzled 16-B chunk (piece k: ^ (k << 5))
+};
+// byte offset inside the page of this lane's 16 B of latent piece k of this wave (2 token rows of 512 B per piece, chunk c
+// of token T stored at chunk c ^ (T & 15))
+__device__ __forceinline__ unsigned dn_off(const PvLane& lc, const int k) {
+  return lc.dn_row + (unsigned)k * 1024u + (lc.dn_x ^ ((unsigned)k << 5));
+}
+
+// scale triples {ks, log2 ks, 1/ks} of a QK wave's 32 tokens (lane li = token 32W + li) -> wave-private scratch
+__device__ __forceinline__ void scale_prep(float* __restrict__ scratch, float ks, const int tok0w, const int li, const int L) {
+  if (tok0w + li >= L || !(ks > 0.f) || !(ks < 3.0e38f)) ks = 1.f;
+  // (both lane halves store the same values to the same addresses: no exec-mask branch)
+  scratch[li] = ks;
+  scratch[32 + li] = __builtin_amdgcn_logf(ks);
+  scratch[64 + li] = __builtin_amdgcn_rcpf(ks);
+}
+
+// ---- QK wave: one page step (block W of page i for row tile rt).  The critical path of a step is this wave's chain
+//      barrier -> K reads -> 12 dependent MFMAs -> softmax -> P' in LDS -> barrier; everything else is moved off it:
+//      the scale triples of the page were written at the end of the previous step, the rope / scale loads of page i+2
+//      go out behind the MFMA issue (into the registers the rope MFMAs just read), the normaliser sums and the next
+//      page's triples follow the P' store.  s_setprio 1 around the MFMA chain: the PV wave of this SIMD has its 8
+//      MFMAs ready at the same time, and they belong beside this wave's softmax, not inside its chain. ----
+__device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w, const QkLane& lc, const int lane,
+                                        const v8i (&qn)[8], const v8bf (&qr)[4], const float qs, RopeRegs& rr,
+                                        const float ks_next, const uint8_t* __restrict__ rope_next,
+                                        const float* __restrict__ scale_next, const uint8_t* __restrict__ kp,
+                                        float* __restrict__ scratch, uint8_t* __restrict__ pbuf_w,
+                                        float* __restrict__ ref_w, const int tok0w, const int L, const int L_row,
+                                        const bool need_mask FL_T_PARAMS) {
+  const int li = lane & 31, lh = lane >> 5;
+#ifndef FL_Y_QK_PRIO
+#define FL_Y_QK_PRIO 1   // 0: no priority; 1: QK waves at priority 1 during their MFMA chain; 2: always
+#endif
+  if (FL_Y_QK_PRIO == 1) __builtin_amdgcn_s_setprio(1);   // (a scheduling barrier for hipcc: it stays OUTSIDE the read / MFMA interleave below)
+  // ---- S^T[32 tok x 32 rows] = K . Q^T ----
+  v16f acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  uint4 ka[8][2];
+  int kb0 = lc.kb0;   // opaque per step: the derived k-step offsets are not kept live across steps
+  asm volatile("" : "+v"(kb0));
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    ka[s][0] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6)) + (s >> 2) * 256);
+    ka[s][1] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6) ^ 16) + (s >> 2) * 256);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(rr.ra[s]), qr[s], acc, 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc, 0, 0, 0, kUnitScale,
+                                                          0, kUnitScale);
+  // operand reads: k-steps 0..3 before the rope MFMAs, k-step 4 + s behind the MFMA of k-step s (four k-steps = 32
+  // registers in flight: with all eight hipcc runs out of registers beside Q and the two rope buffers)
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    // DS reads: k-steps 0..3
+  __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    // rope MFMAs
+  // the scale triples of the lane's 16 tokens take over the operand registers of k-steps 0..3 behind the MFMAs of
+  // k-steps 4..7, so that they have landed when the chain drains ({ks, log2 ks} now, 1/ks behind the scaling: 48
+  // registers at once do not fit beside Q and the rope buffers)
+  float4 ks4[4], lk4[4], ik4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int tb = g * 8 + lh * 4;
+    ks4[g] = *reinterpret_cast<const float4*>(scratch + tb);
+    lk4[g] = *reinterpret_cast<const float4*>(scratch + 32 + tb);
+  }
+#ifndef FL_Y_TRIPLES_IN_CHAIN
+#define FL_Y_TRIPLES_IN_CHAIN 1
+#endif
+#pragma unroll
+  for (int s = 0; s < (FL_Y_TRIPLES_IN_CHAIN ? 8 : 4); ++s) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+  }
+  if (!FL_Y_TRIPLES_IN_CHAIN) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (FL_Y_QK_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+  FL_T(6);   // operand reads + MFMA issue
+#if FL_Y_MID_BARRIER
+  // M_i: this wave's chain is in the matrix pipe; only now do the PV waves issue their MFMAs.  A dependent MFMA becomes
+  // ready just as its predecessor leaves the pipe, so an independent MFMA of the SIMD's other wave wins the slot every
+  // time (priority does not help: nothing of this wave is ready at that moment) and the 12-deep chain took the time of
+  // all 20 MFMAs (measured) while its softmax then found the pipe idle.
+  __builtin_amdgcn_s_barrier();
+  FL_T(11);  // mid-step barrier
+#endif
+  // rope A operand / raw scale of page i+2 into the registers the rope MFMAs have read: token 32W + li, 16-B chunks
+  // 2s + lh of its 128-B row.  UNCONDITIONAL (the caller clamps the page into the part): behind a conditional load hipcc
+  // can only wait with vmcnt(0), which would expose the whole latency of the loads issued one step earlier, every step
+#pragma unroll
+  for (int s = 0; s < 4; ++s) rr.ra[s] = *reinterpret_cast<const uint4*>(rope_next + s * 32);
+  rr.ks = *scale_next;
+  __builtin_amdgcn_sched_barrier(0);
+  FL_T(8);   // rope / scale load issue
+
+  // ---- online softmax of the block; tokens of lane: 32W + 8g + 4lh + e ----
+  float tmax = -INFINITY;
+  if (!need_mask) {
+    // PACKED f32 math (v_pk_mul_f32 / v_pk_fma_f32: two elements per instruction).  Beside a running MFMA a VALU
+    // instruction of either wave of the SIMD gets an issue slot only every ~8 cycles, packed or not: what counts here is
+    // the instruction COUNT of the softmax, not its flops
+    const float2v qs2 = {qs, qs};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float2v y01 = __builtin_elementwise_fma(float2v{acc[g * 4 + 0], acc[g * 4 + 1]} * qs2,
+                                                    float2v{ks4[g].x, ks4[g].y}, float2v{lk4[g].x, lk4[g].y});
+      const float2v y23 = __builtin_elementwise_fma(float2v{acc[g * 4 + 2], acc[g * 4 + 3]} * qs2,
+                                                    float2v{ks4[g].z, ks4[g].w}, float2v{lk4[g].z, lk4[g].w});
+      acc[g * 4 + 0] = y01[0];
+      acc[g * 4 + 1] = y01[1];
+      acc[g * 4 + 2] = y23[0];
+      acc[g * 4 + 3] = y23[1];
+      tmax = fmaxf(fmaxf(tmax, fmaxf(y01[0], y01[1])), fmaxf(y23[0], y23[1]));
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int tb = g * 8 + lh * 4;
+      const float ksv[4] = {ks4[g].x, ks4[g].y, ks4[g].z, ks4[g].w};
+      const float lkv[4] = {lk4[g].x, lk4[g].y, lk4[g].z, lk4[g].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y = fmaf(acc[g * 4 + e] * qs, ksv[e], lkv[e]);
+        if (tok0w + tb + e >= L_row) y = -INFINITY;
+        if (!(y == y)) y = -INFINITY;   // NaN can only come from garbage beyond the row's limit
+        acc[g * 4 + e] = y;
+        tmax = fmaxf(tmax, y);
+      }
+    }
+  }
+  FL_T(9);   // MFMA drain + scaling + max (lanes)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) ik4[g] = *reinterpret_cast<const float4*>(scratch + 64 + g * 8 + lh * 4);
+  {
+    // max over the two lane halves without an LDS round trip: v_permlane32_swap exchanges lanes 32..63 of its first
+    // operand with lanes 0..31 of its second
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+    tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  }
+  FL_T(7);   // MFMA drain + scaling + max
+  const float m_new = tmax > m_w ? ceilf(tmax) + kRefHeadroom : m_w;
+  const float moff = kPShift - m_new;
+  float ev[16];
+  int pk[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float2v a01 = float2v{acc[g * 4 + 0], acc[g * 4 + 1]} + float2v{moff, moff};
+    const float2v a23 = float2v{acc[g * 4 + 2], acc[g * 4 + 3]} + float2v{moff, moff};
+    ev[g * 4 + 0] = __builtin_amdgcn_exp2f(a01[0]);
+    ev[g * 4 + 1] = __builtin_amdgcn_exp2f(a01[1]);
+    ev[g * 4 + 2] = __builtin_amdgcn_exp2f(a23[0]);
+    ev[g * 4 + 3] = __builtin_amdgcn_exp2f(a23[1]);
+    const int v = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 0], ev[g * 4 + 1], 0, false);
+    pk[g] = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 2], ev[g * 4 + 3], v, true);
+  }
+  // publish P' (16 B per lane) and the block reference for the PV waves of this row tile
+  *reinterpret_cast<uint4*>(pbuf_w + lane * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  ref_w[li] = m_new;   // (identical in both lane halves)
+  __builtin_amdgcn_sched_barrier(0);
+  FL_T(10);  // exp + quantise + publish
+  // ---- off the critical path: the two normalisers, then the next page's scale triples ----
+  {
+    const float f = __builtin_amdgcn_exp2f(m_w - m_new);   // exactly 1 when the reference did not move
+    // two partial sums each, as PACKED f32 math (v_pk_fma_f32: nothing of this wave runs on the matrix pipe here)
+    float2v l2 = {l_run * f, 0.f}, q2 = {lq_run * f, 0.f};
+    m_w = m_new;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float2v ik01 = {ik4[g].x, ik4[g].y}, ik23 = {ik4[g].z, ik4[g].w};
+      // unrounded sum: exact LSE
+      l2 = __builtin_elementwise_fma(float2v{ev[g * 4 + 0], ev[g * 4 + 1]}, ik01, l2);
+      l2 = __builtin_elementwise_fma(float2v{ev[g * 4 + 2], ev[g * 4 + 3]}, ik23, l2);
+      // the ROUNDED weights normalise O (numerator and denominator use the same weights: they sum to exactly 1)
+      q2 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(pk[g], false), ik01, q2);
+      q2 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(pk[g], true), ik23, q2);
+    }
+    l_run = l2[0] + l2[1];
+    lq_run = q2[0] + q2[1];
+  }
+  scale_prep(scratch, ks_next, tok0w + kPage, li, L);
+}
+
+// ---- PV wave: O^T[256 dims x 32 rows] += V^T(page) . P^T, with the LDS-DMA refill of a later page in the MFMA shadow ----
+// The reference of O is fixed when a row sees its first valid token and NEVER moves in a pass: later blocks with a larger
+// reference m_b enter with an E8M0 block scale 2^(m_b - m_o) > 1 (exact; fp32 O has the range), so nothing but the MFMA
+// touches O in the page loop (a conditional rescale makes hipcc copy all 128 O registers at the join, every page).  Only
+// a reference more than kMaxUp above m_o cannot be represented: it raises `redo` and the workgroup repeats the request
+// with m_o preset to the final reference.
+constexpr float kMaxUp = 64.f;
+template <bool DMA>
+__device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, const PvLane& lc_in, const int lane,
+                                        const uint8_t* __restrict__ vp, const uint8_t* __restrict__ pbuf_rt,
+                                        const float* __restrict__ ref_rt, const uint8_t* __restrict__ src_nope,
+                                        uint8_t* __restrict__ dma_dst FL_T_PARAMS) {
+  const int li = lane & 31, lh = lane >> 5;
+  // opaque copy of the lane constants: nothing derived from them is hoisted out of the page loop (and spilled)
+  PvLane lc = lc_in;
+  asm volatile("" : "+v"(lc.vb0), "+v"(lc.dn_row), "+v"(lc.dn_x));
+  const uint4 p0 = *reinterpret_cast<const uint4*>(pbuf_rt + lane * 16);
+  const uint4 p1 = *reinterpret_cast<const uint4*>(pbuf_rt + 64 * 16 + lane * 16);
+  const float m0 = ref_rt[li];
+  const float m1 = ref_rt[32 + li];
+  // the refill goes out FIRST: its lead over the page's first reader is what hides the memory latency, and it keeps this
+  // wave's MFMAs out of the QK chain of the SIMD's other wave
+#ifndef FL_Y_DMA_FIRST
+#define FL_Y_DMA_FIRST (FL_Y_MID_BARRIER ? 8 : 0)   // pieces issued before the P' / V^T reads (with the mid-step barrier
+                                                    // this wave has nothing else to do until the QK chains are issued);
+                                                    // the rest goes out one behind each PV MFMA
+#endif
+#if !defined(FL_Y_NODMA) && !defined(FL_Y_NOPV)
+  if (DMA) {
+#pragma unroll
+    for (int k = 0; k < FL_Y_DMA_FIRST; ++k) fl_dma16_s(src_nope, dn_off(lc, k), dma_dst + k * 1024);
+  }
+#endif
+  v8i va[8];
+  auto load_vt = [&](int jb) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint8_t* ap = vp + (lc.vb0 ^ (((jb & 3) << 4) | ((jb >> 2) << 7))) + (u & 1) * (16 * kDN) + (u >> 1) * (32 * kDN);
+      const v2i t2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)ap);
+      va[jb][2 * u] = t2[0];
+      va[jb][2 * u + 1] = t2[1];
+    }
+  };
+  load_vt(0);
+  load_vt(1);
+  load_vt(2);
+#ifdef FL_Y_NOPV   // experiment: PV waves without V^T reads and MFMAs (results are garbage)
+  if (DMA) {
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) fl_dma16_s(src_nope, dn_off(lc, jb), dma_dst + jb * 1024);
+  }
+  m_o = fmaxf(m_o, m0 + m1 + __uint_as_float(p0.x ^ p1.x));
+  return;
+#endif
+  const float mw_max = fmaxf(m0, m1);
+  m_o = m_o > kNegRef ? m_o : mw_max;
+  redo |= (mw_max - m_o > kMaxUp) ? 1 : 0;
+  int sb = 127 + (int)fminf((lh ? m1 : m0) - m_o, kMaxUp);
+  sb = sb < 0 ? 0 : sb;
+  const v8i pb = make_v8i(p0, p1);
+#if FL_Y_MID_BARRIER
+  __builtin_amdgcn_s_barrier();   // M_i: the QK chains are issued
+  FL_T(6);
+#endif
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    if (jb + 3 < 8) load_vt(jb + 3);
+    o[jb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[jb], pb, o[jb], 0, 0, 0, kUnitScale, 0, sb);
+#if !defined(FL_Y_NODMA)
+    if (DMA && jb >= FL_Y_DMA_FIRST) fl_dma16_s(src_nope, dn_off(lc, jb), dma_dst + jb * 1024);
+#endif
+  }
+  // V^T operand reads three tiles ahead of their MFMA
+  if (!FL_Y_MID_BARRIER) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+  for (int jb = 0; jb < 5; ++jb) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(512) void mla_decode_y_kernel(
+    const Params p, const int32_t* __restrict__ g_block_table, const int32_t* __restrict__ g_seqlens,
+    const int32_t* __restrict__ g_meta, const int32_t* __restrict__ g_num_splits,
+    const uint8_t* __restrict__ g_k_nope, const uint16_t* __restrict__ g_k_rope, const float* __restrict__ g_k_scale,
+    const uint8_t* __restrict__ g_q_nope, const uint16_t* __restrict__ g_q_rope, const float* __restrict__ g_q_scale) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[kLdsBytes];
+
+  const int tid = threadIdx.x;
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_pv = wave_id >= 4;
+  const int w4 = wave_id & 3;
+  const int rt = w4 & 1;    // row tile (32 query rows) inside the workgroup
+  const int W = w4 >> 1;    // QK wave: token half; PV wave: d half
+  const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+
+  // ---- workgroup -> (part, row group); the row groups of a part read the same pages: same XCD (block b -> XCD b%8) ----
+  int part, rgrp;
+  {
+    const int id = blockIdx.x;
+    if ((p.num_parts & 7) == 0) {
+      const int xcd = id & 7, k = id >> 3;
+      rgrp = k % p.row_groups;
+      part = (k / p.row_groups) * 8 + xcd;
+    } else {
+      rgrp = id % p.row_groups;
+      part = id / p.row_groups;
+    }
+  }
+  const int32_t* meta = g_meta + part * FL_MLA_META_W;
+  int req = meta[0];
+  int tile_b = meta[1];
+  const int end_req = meta[2];
+  const int end_tile = meta[3];
+  int split_idx = meta[4];
+
+  const int row = rgrp * 64 + rt * 32 + li;   // query row of this lane (both roles: lane&31 = row inside the tile)
+  const bool row_ok = row < p.rows;
+
+#ifdef FL_MLA_TIMING
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+  const unsigned long long tstart = tlast;
+  const unsigned long long wstart = wall_clock64();   // 100 MHz
+#endif
+
+  // per-request geometry shared by both roles
+#define FL_Y_REQUEST_HEAD()                                                                                            \
+  if (req > end_req || (req == end_req && end_tile == 0)) break;                                                       \
+  const int L = g_seqlens[req];                                                                                        \
+  const int nt = L > 0 ? (L + kPage - 1) / kPage : 0;                                                                  \
+  int tile_e = req < end_req ? nt : (end_tile < nt ? end_tile : nt);                                                   \
+  if (tile_e < tile_b) tile_e = tile_b;                                                                                \
+  const int n = tile_e - tile_b;                                                                                       \
+  /* page ids of a 64-page window live in ONE VGPR (lane j = page win_base + j); a lookup is a v_readlane */           \
+  int win_base = 0;                                                                                                    \
+  int pg_vec = 0;                                                                                                      \
+  auto load_window = [&](int base) {                                                                                   \
+    win_base = base;                                                                                                   \
+    const int t = base + lane;                                                                                         \
+    int pg = 0;                                                                                                        \
+    if (t < n) pg = g_block_table[(long long)req * p.bt_stride + tile_b + t];                                          \
+    pg_vec = (pg < 0 || pg >= p.num_pages) ? 0 : pg;                                                                   \
+  };                                                                                                                   \
+  load_window(0);                                                                                                      \
+  auto page_of = [&](int t) { return (long long)__builtin_amdgcn_readlane(pg_vec, t - win_base); }
+
+  const int* redo_flag = reinterpret_cast<const int*>(smem + kOffFlag);
+
+  if (!is_pv) {
+    // =========================== QK waves ===========================
+    QkLane lc;
+    {
+      // K operand: token T = 32W + li, 32 B at d = 64s + 32lh -> 16-B chunks c = 4s + 2lh + e, stored at chunk c ^ (T&15)
+      const int kx = li & 15;
+      lc.kb0 = li * kDN + (((((kx >> 2)) << 2) | ((2 * lh) ^ (kx & 3))) << 4);
+    }
+    float* scratch = reinterpret_cast<float*>(smem + kOffScratch + w4 * kScratchPerWave);
+    if (FL_Y_QK_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+    for (; req < p.bs; ++req, tile_b = 0) {
+      FL_Y_REQUEST_HEAD();
+      // Q fragments (B operands), once per request
+      const long long qrow = (long long)req * p.rows + row;
+      v8i qn[8];
+      v8bf qr[4];
+      float qs = 0.f;
+      if (row_ok) {
+        const uint8_t* qp = g_q_nope + qrow * kDN + lh * 32;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          qn[s] = make_v8i(*reinterpret_cast<const uint4*>(qp + s * 64), *reinterpret_cast<const uint4*>(qp + s * 64 + 16));
+        const uint16_t* rp = g_q_rope + qrow * kDR + lh * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qr[s] = as_bf8(*reinterpret_cast<const uint4*>(rp + s * 16));
+        qs = g_q_scale[qrow] * p.scale_log2e;
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) qn[s] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qr[s] = as_bf8(make_uint4(0, 0, 0, 0));
+      }
+      int L_row = L;
+      if (p.causal) L_row = L - (p.s_q - 1 - row / p.h_q);   // query j sees keys [0, L - (s_q-1-j))
+      if (!row_ok) L_row = 0;
+      const int L_min = p.causal ? L - (p.s_q - 1) : L;
+
+      // rope A operand of this lane: token 32W + li, 16-B chunks 2s + lh of its 128-B row; raw scale of token 32W + li.
+      // Every load is UNCONDITIONAL (page index clamped into the part; an empty part reads the padding page 0).
+      auto rope_src = [&](const int t) {
+        return reinterpret_cast<const uint8_t*>(g_k_rope) + (page_of(t) * kPage + 32 * W + li) * (kDR * 2) + lh * 16;
+      };
+      auto scale_src = [&](const int t) { return g_k_scale + page_of(t) * kPage + 32 * W + li; };
+      auto load_rope = [&](RopeRegs& r, const int t) {
+        const uint8_t* rp = rope_src(t);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) r.ra[s] = *reinterpret_cast<const uint4*>(rp + s * 32);
+        r.ks = *scale_src(t);
+      };
+      for (int pass = 0; pass < 2; ++pass) {
+        float l_run = 0.f, lq_run = 0.f, m_w = kNegRef;
+        RopeRegs rA, rB;
+        if (pass == 1) load_window(0);
+        load_rope(rA, 0);
+        load_rope(rB, n > 1 ? 1 : 0);
+        scale_prep(scratch, rA.ks, tile_b * kPage + 32 * W, li, L);   // (this wave's reads of the previous request are done)
+
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // R0: every wave is done with the LDS of the previous request / pass
+        FL_T(5);   // request prologue
+
+        // step i uses `rr` (page i) and refills it with page i+2; `rn` holds page i+1
+        auto step = [&](const int i, RopeRegs& rr, const RopeRegs& rn) {
+          if (i + 2 >= win_base + 64 && i + 2 < n) load_window(i + 2);   // pages i+2 .. i+65
+          const int t2 = i + 2 < n ? i + 2 : n - 1;
+          const uint8_t* rope_next = rope_src(t2);
+          const float* scale_next = scale_src(t2);
+          FL_T(2);   // (loop control)
+          __builtin_amdgcn_s_barrier();   // B_i: page i landed, P buffers of parity i free
+          FL_T(0);   // barrier
+          const int tok0w = (tile_b + i) * kPage + 32 * W;
+          const bool need_mask = (tile_b + i) * kPage + kPage > L_min;
+          qk_step(l_run, lq_run, m_w, lc, lane, qn, qr, qs, rr, rn.ks, rope_next, scale_next,
+                  smem + kOffRing + (i & 3) * kSlotBytes + W * (32 * kDN), scratch,
+                  smem + kOffPbuf + (i & 1) * kPbufPerParity + (rt * 2 + W) * (64 * 16),
+                  reinterpret_cast<float*>(smem + kOffRef + (i & 1) * kRefPerParity) + (rt * 2 + W) * 32, tok0w, L, L_row,
+                  need_mask FL_T_ARGS);
+          FL_T(1);   // softmax tail + publish (issue)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // P', reference published before the next barrier
+          FL_T(3);   // LDS drain
+        };
+        {
+          // pairs of steps without a condition in between (a skipped second step would leave a path with nothing issued
+          // behind rA's loads: vmcnt(0) again), then the odd tail
+          int i = 0;
+          for (; i + 1 < n; i += 2) {
+            step(i, rA, rB);
+            step(i + 1, rB, rA);
+          }
+          if (i < n) step(i, rA, rB);
+        }
+        __builtin_amdgcn_s_barrier();   // B_n: the PV waves run PV(n-1)
+#if FL_Y_MID_BARRIER
+        __builtin_amdgcn_s_barrier();   // M_n
+#endif
+        // normalisers of this wave's blocks -> LDS for the PV waves' epilogue
+        {
+          const float l_tot = l_run + __shfl_xor(l_run, 32);
+          const float lq_tot = lq_run + __shfl_xor(lq_run, 32);
+          float* lm = reinterpret_cast<float*>(smem + kOffLm) + (rt * 2 + W) * 96;
+          if (lh == 0) {
+            lm[li] = l_tot;
+            lm[32 + li] = lq_tot;
+            lm[64 + li] = m_w;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // E0
+        FL_T(4);   // B_n, normalisers, E0
+        if (pass == 1) break;
+        if ((redo_flag[0] | redo_flag[1] | redo_flag[2] | redo_flag[3]) == 0) break;   // workgroup-uniform
+      }
+    }
+#ifdef FL_MLA_TIMING
+    if (g_dbg_y != nullptr && lane == 0) {
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(g_dbg_y) + ((long long)blockIdx.x * 8 + wave_id) * 14;
+      for (int i = 0; i < 12; ++i) d[i] = tacc[i];
+      d[12] = __builtin_readcyclecounter() - tstart;
+      d[13] = wall_clock64() - wstart;
+    }
+#endif
+    return;
+  }
+
+  // =========================== PV waves ===========================
+  PvLane lc;
+  {
+    const int s16 = lane & 15;
+    const int gi = (lane >> 4) & 1;
+    const int tj = s16 >> 1;
+    const int tok_in8 = (tj & 3) + ((tj >> 2) << 3);
+    const int vrow = 4 * lh + tok_in8;
+    lc.vb0 = vrow * kDN + ((((gi << 2)) ^ (vrow & 15)) << 4) + (s16 & 1) * 8;
+    // latent DMA piece k of this wave: token row T = (w4*8 + k)*2 + lh, chunk li stored from source chunk li ^ (T&15)
+    lc.dn_row = (unsigned)((w4 * kPiecesPerWave * 2 + lh) * kDN);
+    lc.dn_x = (unsigned)((li ^ lh) << 4);
+  }
+  for (; req < p.bs; ++req, tile_b = 0, split_idx = 0) {
+    FL_Y_REQUEST_HEAD();
+    const int split_base = g_num_splits[req];
+    const bool is_split = (g_num_splits[req + 1] - split_base) > 1;
+    auto ring = [&](int t) { return smem + kOffRing + (t & 3) * kSlotBytes; };
+    auto src_of = [&](int t) { return g_k_nope + page_of(t) * (long long)(kPage * kDN); };
+    auto issue_page = [&](int t) {
+      const uint8_t* sn = src_of(t);
+      uint8_t* dst = ring(t) + w4 * (kPiecesPerWave * 1024);
+#pragma unroll
+      for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s(sn, dn_off(lc, k), dst + k * 1024);
+    };
+    const float* lm = reinterpret_cast<const float*>(smem + kOffLm) + rt * 192;
+
+    v16f o[8];
+    float m_o = kNegRef;
+    float mo_preset = kNegRef;
+    // pass 0 fixes the O reference at each row's first valid page; pass 1 runs only if some block reference outran it
+    // by more than kMaxUp (pv_step), with the reference preset to the final one
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+      m_o = mo_preset;
+      int redo = 0;
+      if (pass == 1) load_window(0);
+
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // R0
+      if (n > 0) issue_page(0);
+      if (n > 1) issue_page(1);
+      FL_T(5);   // request prologue
+
+      // step i: wait for page i, barrier B_i, PV(i-1) with the refill of page i+2 in its MFMA shadow, tail fill of page i.
+      // The steps with a refill and the last two without are separate loops, each with ONE step variant (two variants
+      // joined inside a loop make hipcc copy the O registers at the join).
+#define FL_Y_PV_STEP(HAS_PREV, HAS_DMA)                                                                                \
+  {                                                                                                                    \
+    if (FL_Y_NOWAIT) { /* experiment: timing without the page-landed wait (results are garbage) */                     \
+    } else if (i + 1 < n) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* page i landed, page i+1 may stay in flight */ \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+    FL_T(0); /* page-landed wait */                                                                                    \
+    __builtin_amdgcn_s_barrier(); /* B_i */                                                                            \
+    FL_T(1); /* barrier */                                                                                             \
+    if (HAS_DMA && i + 2 >= win_base + 64) load_window(i + 2);                                                         \
+    const uint8_t* sn = HAS_DMA ? src_of(i + 2) : nullptr;                                                             \
+    uint8_t* dst = ring(i + 2) + w4 * (kPiecesPerWave * 1024);                                                         \
+    if (HAS_PREV) {                                                                                                    \
+      pv_step<HAS_DMA>(o, m_o, redo, lc, lane, ring(i - 1) + W * 256,                                                  \
+                       smem + kOffPbuf + ((i - 1) & 1) * kPbufPerParity + rt * (2 * 64 * 16),                          \
+                       reinterpret_cast<const float*>(smem + kOffRef + ((i - 1) & 1) * kRefPerParity) + rt * 64, sn,   \
+                       dst FL_T_ARGS);                                                                                 \
+    } else {                                                                                                           \
+      if (HAS_DMA) {                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s(sn, dn_off(lc, k), dst + k * 1024);      \
+      }                                                                                                                \
+      if (FL_Y_MID_BARRIER) __builtin_amdgcn_s_barrier(); /* M_i */                                                    \
+    }                                                                                                                  \
+    /* tail of the sequence: zero the rows of page i past the end (P' is exactly 0 there, but 0 * NaN from stale fp8   \
+       NaN patterns would poison the PV MFMA of the next step); the QK waves mask those tokens by index */             \
+    if (i < n && (tile_b + i) * kPage + kPage > L) {                                                                   \
+      const int nvalid = L - (tile_b + i) * kPage;                                                                     \
+      uint8_t* wr = ring(i);                                                                                           \
+      _Pragma("clang loop vectorize(disable) unroll(disable)")                                                         \
+      for (int T = nvalid + 2 * w4 + lh; T < kPage; T += 8)                                                            \
+        *reinterpret_cast<uint4*>(wr + T * kDN + li * 16) = make_uint4(0, 0, 0, 0);                                    \
+    }                                                                                                                  \
+    FL_T(2); /* PV + refill issue */                                                                                   \
+  }
+      {
+        int i = 0;
+        if (n > 2) FL_Y_PV_STEP(false, true) else FL_Y_PV_STEP(false, false)
+        for (i = 1; i + 2 < n; ++i) FL_Y_PV_STEP(true, true)
+        for (; i <= n; ++i) FL_Y_PV_STEP(true, false)
+      }
+#undef FL_Y_PV_STEP
+      // workgroup-uniform redo decision (the page loop has workgroup barriers)
+      if (lane == 0) reinterpret_cast<int*>(smem + kOffFlag)[w4] = (pass == 0 && __any(redo != 0)) ? 1 : 0;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // E0: normalisers of the QK waves and the redo votes are in LDS, the ring is free
+      FL_T(3);   // E0
+      if (pass == 1) break;
+      if ((redo_flag[0] | redo_flag[1] | redo_flag[2] | redo_flag[3]) == 0) break;
+      mo_preset = fmaxf(lm[64 + li], lm[96 + 64 + li]);   // final references of the two blocks
+    }
+
+    // ---- per-request epilogue: merge the normalisers of the two blocks, normalise, store this wave's d half ----
+    const float mA = lm[64 + li], mB = lm[96 + 64 + li];
+    const float fA = __builtin_amdgcn_exp2f(mA - m_o), fB = __builtin_amdgcn_exp2f(mB - m_o);   // <= 2^kMaxUp
+    const float l = lm[li] * fA + lm[96 + li] * fB;
+    const float lq = lm[32 + li] * fA + lm[96 + 32 + li] * fB;
+    const float inv = lq > 0.f ? 1.f / lq : 0.f;
+    const float lse_nat = l > 0.f ? (__builtin_amdgcn_logf(l) + m_o - kPShift) * 0.6931471805599453f : -INFINITY;
+    // split-KV partials are normalised by lq, so they are COMBINED with lq-based weights; the exact LSE travels along
+    const float lseq_nat = lq > 0.f ? (__builtin_amdgcn_logf(lq) + m_o - kPShift) * 0.6931471805599453f : -INFINITY;
+    const int slot_idx = split_base + split_idx;
+    if (row_ok && lh == 0 && W == 0) {
+      if (is_split) {
+        p.lse_accum[((long long)slot_idx * p.rows + row) * 2 + 0] = lseq_nat;
+        p.lse_accum[((long long)slot_idx * p.rows + row) * 2 + 1] = lse_nat;
+      } else {
+        const int j = row / p.h_q, h = row - j * p.h_q;
+        p.lse[((long long)req * p.h_q + h) * p.s_q + j] = lse_nat;
+      }
+    }
+    // O -> memory through a wave-private LDS transpose (the ring is free now).  A lane holds ONE row, 4 dims at a
+    // time: stored directly, every store instruction would touch 64 rows x 8 B.  Tiles 4c..4c+3 cover the contiguous
+    // dims [256W + 128c, +128) (C row i = e + 8g + 4lh of tile 4c + jq is d = 128c + 16jq + (i&15) + 64(i>>4)), so
+    // chunk c is staged as [32 rows][128 f32] (+4 pad) and leaves as 256-B bf16 row segments.
+    {
+      float* stg = reinterpret_cast<float*>(smem + kOffRing) + w4 * (32 * kStgStride);
+      const int row0 = rgrp * 64 + rt * 32;
+      uint16_t* dst = is_split ? reinterpret_cast<uint16_t*>(p.o_accum) + ((long long)slot_idx * p.rows + row0) * kDN
+                               : p.out + ((long long)req * p.rows + row0) * kDN;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int d_off = 16 * jq + 8 * (g & 1) + 4 * lh + 64 * (g >> 1);
+            *reinterpret_cast<float4*>(stg + li * kStgStride + d_off) =
+                make_float4(o[4 * c + jq][g * 4 + 0] * inv, o[4 * c + jq][g * 4 + 1] * inv,
+                            o[4 * c + jq][g * 4 + 2] * inv, o[4 * c + jq][g * 4 + 3] * inv);
+          }
+        uint16_t* dbase = dst + 256 * W + 128 * c + (lane & 15) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = (lane >> 4) + 4 * k;
+          const float4 v0 = *reinterpret_cast<const float4*>(stg + r * kStgStride + (lane & 15) * 8);
+          const float4 v1 = *reinterpret_cast<const float4*>(stg + r * kStgStride + (lane & 15) * 8 + 4);
+          uint4 ov;   // v_cvt_pk_bf16_f32: RNE, two values per instruction
+          ov.x = fl_pack_bf16(v0.x, v0.y);
+          ov.y = fl_pack_bf16(v0.z, v0.w);
+          ov.z = fl_pack_bf16(v1.x, v1.y);
+          ov.w = fl_pack_bf16(v1.z, v1.w);
+          if (row0 + r < p.rows) *reinterpret_cast<uint4*>(dbase + (long long)r * kDN) = ov;
+        }
+      }
+    }
+    FL_T(4);   // epilogue
+  }
+#undef FL_Y_REQUEST_HEAD
+#ifdef FL_MLA_TIMING
+  if (g_dbg_y != nullptr && lane == 0) {
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(g_dbg_y) + ((long long)blockIdx.x * 8 + wave_id) * 14;
+    for (int i = 0; i < 12; ++i) d[i] = tacc[i];
+    d[12] = __builtin_readcyclecounter() - tstart;
+    d[13] = wall_clock64() - wstart;
+  }
+#endif
+}
+
+}  // namespace
+
+int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipStream_t stream) {
+  Params p = p_in;
+  p.row_groups = (p.rows + 63) / 64;
+  p.partial_bf16 = 1;   // split partials travel as bf16 rows
+  const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(512);
+  mla_decode_y_kernel<<<grid, block, 0, stream>>>(
+      p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, a->num_splits, (const uint8_t*)a->k_nope,
+      (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
+  FL_CHECK_LAUNCH("mla_decode_y_kernel");
+  return fl_mla_launch_combine(p, a->num_splits, stream);
+}
+
+#ifdef FL_MLA_TIMING
+extern "C" int fl_mla_debug_set_buffer_y(int* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_y), &dev_ptr, sizeof(dev_ptr));
+}
+#endif
