@@ -28,8 +28,8 @@ torch.cuda.synchronize()
 d = dbg.cpu().numpy().view(np.uint64).reshape(nblocks, 8, REC).astype(np.float64)
 steps = (seq // 64) * bs / meta.shape[0]
 TICK = 10.0   # print unit: ticks x 10 (the counter runs at roughly the shader clock: read 'ns' as 0.1 ticks)
-for role, sl, names in (("QK waves", slice(0, 4), ["barrier wait", "QK+softmax+publish", "loop control", "rope issue + LDS drain", "B_n+normalisers+E0", "request prologue", "  reads+MFMA issue", "  ik reads + cross-half max", "  rope/scale load issue", "  MFMA drain+scale+max(lanes)", "  exp+quantise+publish", "-"]),
-                        ("PV waves", slice(4, 8), ["page-landed wait (vmcnt)", "barrier wait", "PV + refill issue + tail fill", "E0", "epilogue (store)", "request prologue", "-", "-", "-", "-", "-", "-"])):
+for role, sl, names in (("QK waves", slice(0, 4), ["barrier wait B", "after M: chain rest, sums, triples", "loop control", "LDS drain", "E0 etc", "request prologue", "B..M: chain || softmax(prev)", "mid barrier M wait", "-", "-", "-", "-"]),
+                        ("PV waves", slice(4, 8), ["page-landed wait (vmcnt)", "barrier wait B", "refill issue + first V^T reads", "E0", "epilogue (store)", "request prologue", "mid barrier M wait", "PV MFMAs + tail fill", "-", "-", "-", "-"])):
     x = d[:, sl, :].reshape(-1, REC)
     life = x[:, 12]
     print(f"   shader clock while the waves ran: {(x[:, 12] / (x[:, 13] * 10.0)).mean():.2f} GHz (s_memtime cycles / wall_clock64 ns); wave wall time {x[:, 13].mean() / 100:.1f} us")
