@@ -28,15 +28,13 @@ using namespace fl_mla;
 
 namespace {
 
-constexpr int kOffRing = 0;                                        // 4 x 32 KiB latent pages
-constexpr int kRopeSlots = 3;
-constexpr int kOffRope = kOffRing + kRingSlots * kSlotBytes;       // 3 x 8 KiB rope pages (bf16)
-constexpr int kOffPbuf = kOffRope + kRopeSlots * kRopeBytes;       // [rt 2][W 2][64 lanes][16 B]: P' of ONE page
-constexpr int kPbufBytes = 2 * 2 * 64 * 16;
-constexpr int kOffRef = kOffPbuf + kPbufBytes;                     // [rt 2][W 2][32 rows] f32: block references
-constexpr int kRefBytes = 2 * 2 * 32 * 4;
+constexpr int kOffRing = 0;                                        // 4 x 32 KiB
+constexpr int kPbufPerParity = 2 * 2 * 64 * 16;                    // [rt 2][W 2][64 lanes][16 B]
+constexpr int kOffPbuf = kOffRing + kRingSlots * kSlotBytes;       // [parity 2]
+constexpr int kRefPerParity = 2 * 2 * 32 * 4;                      // [rt 2][W 2][32 rows] f32
+constexpr int kOffRef = kOffPbuf + 2 * kPbufPerParity;             // [parity 2]
 constexpr int kScratchPerWave = 3 * 32 * 4;                        // {ks, log2 ks, 1/ks} x 32 tokens
-constexpr int kOffScratch = kOffRef + kRefBytes;                   // [QK wave 4]
+constexpr int kOffScratch = kOffRef + 2 * kRefPerParity;           // [QK wave 4]
 constexpr int kOffLm = kOffScratch + 4 * kScratchPerWave;          // [rt 2][W 2][3][32] f32: l, lq, m per row
 constexpr int kOffFlag = kOffLm + 2 * 2 * 3 * 32 * 4;              // 4 ints: redo votes of the PV waves
 constexpr int kLdsBytes = kOffFlag + 16;
@@ -44,12 +42,14 @@ static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 constexpr int kStgStride = 128 + 4;                                // epilogue staging: floats per row (in the ring)
 static_assert(4 * 32 * kStgStride * 4 <= kRingSlots * kSlotBytes, "epilogue staging fits the ring");
 
-constexpr int kPiecesPerWave = kDmaNopePerTile / 4;                // 8 latent LDS-DMA pieces of 1 KiB per PV wave and page
-constexpr int kRopePiecesPerWave = 2;                              // + 2 rope pieces (8 token rows of 128 B each)
-constexpr int kDmaPerWavePage = kPiecesPerWave + kRopePiecesPerWave;   // 10: the counted vmcnt waits rely on it
+constexpr int kPiecesPerWave = kDmaNopePerTile / 4;                // 8 LDS-DMA pieces of 1 KiB per PV wave and page
 
 #ifndef FL_Y_NOWAIT
 #define FL_Y_NOWAIT 0
+#endif
+#ifndef FL_Y_MID_BARRIER
+#define FL_Y_MID_BARRIER 0   // experiment (measured slower: 134.7 vs 127-133 us): second barrier per step between the QK
+                             // waves' MFMA chain and the PV waves' MFMAs
 #endif
 #ifdef FL_MLA_TIMING
 __device__ int* g_dbg_y = nullptr;   // debug builds only: set by fl_mla_debug_set_buffer_y
@@ -62,54 +62,24 @@ __device__ int* g_dbg_y = nullptr;   // debug builds only: set by fl_mla_debug_s
 #define FL_T_ARGS
 #endif
 
+// Rope A operand (4 bf16 k-steps) and raw k_scale of one page for one QK wave, held in registers two pages ahead.
+struct RopeRegs {
+  uint4 ra[4];
+  float ks;
+};
 
 struct QkLane {
-  int rb0;   // rope operand: byte offset inside a rope slot for k-step 0 (k-step s: ^ (s << 5)); + W*4096
   int kb0;   // K operand: byte offset inside a slot for k-step 0, first 16 B (second: ^16); k-step s: ^ ((s&3) << 6), + (s>>2)*256
 };
 struct PvLane {
   int vb0;          // V^T tr8 source of tile jb = 0 (tile jb: ^ ((jb&3) << 4) ^ ((jb>>2) << 7)); + u immediates; + Wd*256
   unsigned dn_row;  // latent DMA: byte offset of this lane's token row of piece 0 of this wave (piece k: + k * 1024)
   unsigned dn_x;    // ... and its swizzled 16-B chunk (piece k: ^ (k << 5))
-  unsigned dr[kRopePiecesPerWave];   // rope DMA: byte offset of this lane's 16 B inside the page's rope block
 };
-// Four consecutive 1-KiB LDS-DMA pieces behind ONE M0 write: the instruction's immediate offset is added to the global
-// address AND to the LDS address (M0 + offset + 16 * lane), so pieces whose source and destination both advance by 1 KiB
-// only differ in that immediate (13-bit signed: 0..3 KiB) and in the swizzle of the per-lane offset.
-template <int K0, int N>
-__device__ __forceinline__ void dma_group(const uint8_t* sbase, const unsigned voff0, const unsigned (&xorv)[4],
-                                          const uint8_t* lds_dst) {
-  const int la = __builtin_amdgcn_readfirstlane((int)(uintptr_t)lds_dst);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(la) : "memory", "m0");
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const unsigned v = voff0 ^ xorv[k];
-    if (k == 0) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(v), "s"(sbase) : "memory", "m0");
-    if (k == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(v), "s"(sbase) : "memory", "m0");
-    if (k == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(v), "s"(sbase) : "memory", "m0");
-    if (k == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(v), "s"(sbase) : "memory", "m0");
-  }
-}
-// all DMA pieces of one page for one PV wave: 2 rope pieces + 8 latent pieces (kDmaPerWavePage = 10 instructions)
-struct PvLane;
-__device__ __forceinline__ void dma_page_pieces(const PvLane& lc, const uint8_t* src_rope, uint8_t* dst_rope,
-                                                const uint8_t* src_nope, uint8_t* dst_nope);
 // byte offset inside the page of this lane's 16 B of latent piece k of this wave (2 token rows of 512 B per piece, chunk c
 // of token T stored at chunk c ^ (T & 15))
 __device__ __forceinline__ unsigned dn_off(const PvLane& lc, const int k) {
   return lc.dn_row + (unsigned)k * 1024u + (lc.dn_x ^ ((unsigned)k << 5));
-}
-__device__ __forceinline__ void dma_page_pieces(const PvLane& lc, const uint8_t* src_rope, uint8_t* dst_rope,
-                                                const uint8_t* src_nope, uint8_t* dst_nope) {
-  // rope piece k: source offset dr[0] ^ (k << 6), + k KiB (the row swizzle (T >> 1) & 7 flips bit 2 with k)
-  const unsigned xr[4] = {0u, 64u, 0u, 0u};
-  dma_group<0, kRopePiecesPerWave>(src_rope, lc.dr[0], xr, dst_rope);
-  // latent piece k: source offset dn_row + (dn_x ^ (k << 5)), + k KiB (dn_row is a multiple of 512: the XOR of the
-  // 16-B chunk bits 5..7 commutes with the sum)
-  const unsigned voff = lc.dn_row + lc.dn_x;
-  const unsigned x0[4] = {0u, 32u, 64u, 96u}, x1[4] = {128u, 160u, 192u, 224u};
-  dma_group<0, 4>(src_nope, voff, x0, dst_nope);
-  dma_group<4, 4>(src_nope + 4096, voff, x1, dst_nope + 4096);
 }
 
 // scale triples {ks, log2 ks, 1/ks} of a QK wave's 32 tokens (lane li = token 32W + li) -> wave-private scratch
@@ -121,214 +91,162 @@ __device__ __forceinline__ void scale_prep(float* __restrict__ scratch, float ks
   scratch[64 + li] = __builtin_amdgcn_rcpf(ks);
 }
 
-// ---- QK wave: one page step.  Beside a running MFMA every other instruction of the SIMD is (almost) free, and a wave
-//      alone issues in order: the 12-deep dependent MFMA chain of a block blocks its wave for ~800 cycles, and the ~130
-//      VALU instructions of a block's softmax cost ~5 cycles each behind it (measured: 2700 cycles per step, the matrix
-//      pipe 35 % busy).  So a step is software-pipelined across TWO pages and split by a second barrier:
-//        B_i   page i landed
-//              QK chain of page i (4 bf16 rope + 8 MX-fp8 MFMAs into acc_cur), one SLOT per MFMA; in the slots: the softmax of
-//              page i-1 (its S^T waits in y_prev since the previous step) up to the P' / reference store, the operand
-//              reads four k-steps ahead, the rope / scale loads of page i+2
-//        M_i   P'(i-1) is in LDS -> the PV waves run PV(i-1) now, beside the rest of this wave's step:
-//              the last chain MFMAs, the normaliser sums of page i-1, the scale triples of page i
-//      (P' is written before M_i and read after it: ONE buffer).  sched_barrier(0) fences the slots: the software
-//      pipeline is fixed in the source. ----
-#define FL_SLOT_END() __builtin_amdgcn_sched_barrier(0)
-constexpr int kMidSlot = 9;
-
-// The chain's MFMAs are inline asm: as builtins they are register-only instructions without side effects, and hipcc
-// sinks them towards their only consumer — the NEXT step's softmax — across both barriers.  (The S accumulator is read
-// by VALU instructions a whole step later: no XDL-write -> VALU-read wait states are needed here.)
-__device__ __forceinline__ v4i y_as_v4i(const uint4 a) { return v4i{(int)a.x, (int)a.y, (int)a.z, (int)a.w}; }
-__device__ __forceinline__ v4i y_as_v4i(const v8bf b) {
-  union { v8bf b; v4i i; } x;
-  x.b = b;
-  return x.i;
-}
-__device__ __forceinline__ void mfma_rope_first(v16f& acc, const uint4 a, const v8bf b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(y_as_v4i(a)), "v"(y_as_v4i(b)));
-}
-__device__ __forceinline__ void mfma_rope(v16f& acc, const uint4 a, const v8bf b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(y_as_v4i(a)), "v"(y_as_v4i(b)));
-}
-__device__ __forceinline__ void mfma_fp8(v16f& acc, const v8i a, const v8i b) {
-  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
-               : "+v"(acc)
-               : "v"(a), "v"(b), "v"(kUnitScale));
-}   // M_i sits behind MFMA slot kMidSlot (0..3 rope, 4..11 latent)
-
-template <bool HAS_CUR, bool HAS_PREV, bool MASK>
-__device__ __forceinline__ void qk_step(v16f& acc_cur, v16f& y_prev, float& l_run, float& lq_run, float& m_w,
-                                        const QkLane& lc, const int lane, const v8i (&qn)[8], const v8bf (&qr)[4],
-                                        const float qs, float& ks_reg, const float* __restrict__ scale_next,
-                                        const uint8_t* __restrict__ kp, const uint8_t* __restrict__ rp,
+// ---- QK wave: one page step (block W of page i for row tile rt).  The critical path of a step is this wave's chain
+//      barrier -> K reads -> 12 dependent MFMAs -> softmax -> P' in LDS -> barrier; everything else is moved off it:
+//      the scale triples of the page were written at the end of the previous step, the rope / scale loads of page i+2
+//      go out behind the MFMA issue (into the registers the rope MFMAs just read), the normaliser sums and the next
+//      page's triples follow the P' store.  s_setprio 1 around the MFMA chain: the PV wave of this SIMD has its 8
+//      MFMAs ready at the same time, and they belong beside this wave's softmax, not inside its chain. ----
+__device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w, const QkLane& lc, const int lane,
+                                        const v8i (&qn)[8], const v8bf (&qr)[4], const float qs, RopeRegs& rr,
+                                        const float ks_next, const uint8_t* __restrict__ rope_next,
+                                        const float* __restrict__ scale_next, const uint8_t* __restrict__ kp,
                                         float* __restrict__ scratch, uint8_t* __restrict__ pbuf_w,
-                                        float* __restrict__ ref_w, const int tok0w_cur, const int tok0w_prev, const int L,
-                                        const int L_row FL_T_PARAMS) {
-  // MASK = false: every token of page i-1 is valid for every row of the wave (no selects); MASK = true: the pages around
-  // the end of a sequence (rows past the end, causal limits of s_q > 1)
-  constexpr bool need_mask_prev = MASK;
+                                        float* __restrict__ ref_w, const int tok0w, const int L, const int L_row,
+                                        const bool need_mask FL_T_PARAMS) {
   const int li = lane & 31, lh = lane >> 5;
-#if defined(FL_Y_NOCOMPUTE) || defined(FL_Y_NOQK)   // experiment: the DMA stream alone / PV waves alone (results are garbage)
-  __builtin_amdgcn_s_barrier();   // M_i
-  return;
+#ifndef FL_Y_QK_PRIO
+#define FL_Y_QK_PRIO 1   // 0: no priority; 1: QK waves at priority 1 during their MFMA chain; 2: always
 #endif
-  const float ks_cur = ks_reg;   // raw scale of page i (the register is refilled with page i+2 below)
-  // ---- softmax of page i-1 in pieces ----
-  float4 ks4[2], lk4[2], ik4[4];   // {ks, log2 ks} of two groups at a time; 1/ks of all four for the tail
-  float tmax = -INFINITY, m_new = m_w, moff = 0.f;
-  int pk[4];   // (the exponentials overwrite y_prev in place)
-  auto load_kl = [&](const int g) {
-    ks4[g & 1] = *reinterpret_cast<const float4*>(scratch + g * 8 + lh * 4);
-    lk4[g & 1] = *reinterpret_cast<const float4*>(scratch + 32 + g * 8 + lh * 4);
-  };
-  auto scale_g = [&](const int g) {   // y = s * qs * ks + log2 ks; running max
-    const float4 k4 = ks4[g & 1], l4 = lk4[g & 1];
-    if (!need_mask_prev) {
-      const float2v qs2 = {qs, qs};
-      const float2v y01 = __builtin_elementwise_fma(float2v{y_prev[g * 4 + 0], y_prev[g * 4 + 1]} * qs2, float2v{k4.x, k4.y},
-                                                    float2v{l4.x, l4.y});
-      const float2v y23 = __builtin_elementwise_fma(float2v{y_prev[g * 4 + 2], y_prev[g * 4 + 3]} * qs2, float2v{k4.z, k4.w},
-                                                    float2v{l4.z, l4.w});
-      y_prev[g * 4 + 0] = y01[0];
-      y_prev[g * 4 + 1] = y01[1];
-      y_prev[g * 4 + 2] = y23[0];
-      y_prev[g * 4 + 3] = y23[1];
+  if (FL_Y_QK_PRIO == 1) __builtin_amdgcn_s_setprio(1);   // (a scheduling barrier for hipcc: it stays OUTSIDE the read / MFMA interleave below)
+  // ---- S^T[32 tok x 32 rows] = K . Q^T ----
+  v16f acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  uint4 ka[8][2];
+  int kb0 = lc.kb0;   // opaque per step: the derived k-step offsets are not kept live across steps
+  asm volatile("" : "+v"(kb0));
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    ka[s][0] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6)) + (s >> 2) * 256);
+    ka[s][1] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6) ^ 16) + (s >> 2) * 256);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(rr.ra[s]), qr[s], acc, 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc, 0, 0, 0, kUnitScale,
+                                                          0, kUnitScale);
+  // operand reads: k-steps 0..3 before the rope MFMAs, k-step 4 + s behind the MFMA of k-step s (four k-steps = 32
+  // registers in flight: with all eight hipcc runs out of registers beside Q and the two rope buffers)
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    // DS reads: k-steps 0..3
+  __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    // rope MFMAs
+  // the scale triples of the lane's 16 tokens take over the operand registers of k-steps 0..3 behind the MFMAs of
+  // k-steps 4..7, so that they have landed when the chain drains ({ks, log2 ks} now, 1/ks behind the scaling: 48
+  // registers at once do not fit beside Q and the rope buffers)
+  float4 ks4[4], lk4[4], ik4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int tb = g * 8 + lh * 4;
+    ks4[g] = *reinterpret_cast<const float4*>(scratch + tb);
+    lk4[g] = *reinterpret_cast<const float4*>(scratch + 32 + tb);
+  }
+#ifndef FL_Y_TRIPLES_IN_CHAIN
+#define FL_Y_TRIPLES_IN_CHAIN 1
+#endif
+#pragma unroll
+  for (int s = 0; s < (FL_Y_TRIPLES_IN_CHAIN ? 8 : 4); ++s) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+  }
+  if (!FL_Y_TRIPLES_IN_CHAIN) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (FL_Y_QK_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+  FL_T(6);   // operand reads + MFMA issue
+#if FL_Y_MID_BARRIER
+  // M_i: this wave's chain is in the matrix pipe; only now do the PV waves issue their MFMAs.  A dependent MFMA becomes
+  // ready just as its predecessor leaves the pipe, so an independent MFMA of the SIMD's other wave wins the slot every
+  // time (priority does not help: nothing of this wave is ready at that moment) and the 12-deep chain took the time of
+  // all 20 MFMAs (measured) while its softmax then found the pipe idle.
+  __builtin_amdgcn_s_barrier();
+  FL_T(11);  // mid-step barrier
+#endif
+  // rope A operand / raw scale of page i+2 into the registers the rope MFMAs have read: token 32W + li, 16-B chunks
+  // 2s + lh of its 128-B row.  UNCONDITIONAL (the caller clamps the page into the part): behind a conditional load hipcc
+  // can only wait with vmcnt(0), which would expose the whole latency of the loads issued one step earlier, every step
+#pragma unroll
+  for (int s = 0; s < 4; ++s) rr.ra[s] = *reinterpret_cast<const uint4*>(rope_next + s * 32);
+  rr.ks = *scale_next;
+  __builtin_amdgcn_sched_barrier(0);
+  FL_T(8);   // rope / scale load issue
+
+  // ---- online softmax of the block; tokens of lane: 32W + 8g + 4lh + e ----
+  float tmax = -INFINITY;
+  if (!need_mask) {
+    // PACKED f32 math (v_pk_mul_f32 / v_pk_fma_f32: two elements per instruction).  Beside a running MFMA a VALU
+    // instruction of either wave of the SIMD gets an issue slot only every ~8 cycles, packed or not: what counts here is
+    // the instruction COUNT of the softmax, not its flops
+    const float2v qs2 = {qs, qs};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float2v y01 = __builtin_elementwise_fma(float2v{acc[g * 4 + 0], acc[g * 4 + 1]} * qs2,
+                                                    float2v{ks4[g].x, ks4[g].y}, float2v{lk4[g].x, lk4[g].y});
+      const float2v y23 = __builtin_elementwise_fma(float2v{acc[g * 4 + 2], acc[g * 4 + 3]} * qs2,
+                                                    float2v{ks4[g].z, ks4[g].w}, float2v{lk4[g].z, lk4[g].w});
+      acc[g * 4 + 0] = y01[0];
+      acc[g * 4 + 1] = y01[1];
+      acc[g * 4 + 2] = y23[0];
+      acc[g * 4 + 3] = y23[1];
       tmax = fmaxf(fmaxf(tmax, fmaxf(y01[0], y01[1])), fmaxf(y23[0], y23[1]));
-    } else {
-      const float ksv[4] = {k4.x, k4.y, k4.z, k4.w};
-      const float lkv[4] = {l4.x, l4.y, l4.z, l4.w};
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int tb = g * 8 + lh * 4;
+      const float ksv[4] = {ks4[g].x, ks4[g].y, ks4[g].z, ks4[g].w};
+      const float lkv[4] = {lk4[g].x, lk4[g].y, lk4[g].z, lk4[g].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float y = fmaf(y_prev[g * 4 + e] * qs, ksv[e], lkv[e]);
-        if (tok0w_prev + g * 8 + lh * 4 + e >= L_row) y = -INFINITY;
+        float y = fmaf(acc[g * 4 + e] * qs, ksv[e], lkv[e]);
+        if (tok0w + tb + e >= L_row) y = -INFINITY;
         if (!(y == y)) y = -INFINITY;   // NaN can only come from garbage beyond the row's limit
-        y_prev[g * 4 + e] = y;
+        acc[g * 4 + e] = y;
         tmax = fmaxf(tmax, y);
       }
     }
-  };
-  auto ref_piece = [&]() {
+  }
+  FL_T(9);   // MFMA drain + scaling + max (lanes)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) ik4[g] = *reinterpret_cast<const float4*>(scratch + 64 + g * 8 + lh * 4);
+  {
     // max over the two lane halves without an LDS round trip: v_permlane32_swap exchanges lanes 32..63 of its first
     // operand with lanes 0..31 of its second
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
     tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    m_new = tmax > m_w ? ceilf(tmax) + kRefHeadroom : m_w;
-    moff = kPShift - m_new;
-  };
-  auto exp_g = [&](const int g) {
-    const float2v a01 = float2v{y_prev[g * 4 + 0], y_prev[g * 4 + 1]} + float2v{moff, moff};
-    const float2v a23 = float2v{y_prev[g * 4 + 2], y_prev[g * 4 + 3]} + float2v{moff, moff};
-    y_prev[g * 4 + 0] = __builtin_amdgcn_exp2f(a01[0]);
-    y_prev[g * 4 + 1] = __builtin_amdgcn_exp2f(a01[1]);
-    y_prev[g * 4 + 2] = __builtin_amdgcn_exp2f(a23[0]);
-    y_prev[g * 4 + 3] = __builtin_amdgcn_exp2f(a23[1]);
-    const int v = __builtin_amdgcn_cvt_pk_fp8_f32(y_prev[g * 4 + 0], y_prev[g * 4 + 1], 0, false);
-    pk[g] = __builtin_amdgcn_cvt_pk_fp8_f32(y_prev[g * 4 + 2], y_prev[g * 4 + 3], v, true);
-  };
-  auto publish = [&]() {
-    *reinterpret_cast<uint4*>(pbuf_w + lane * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-    ref_w[li] = m_new;   // (identical in both lane halves)
-  };
-  // piece k of the previous page's softmax (runs in MFMA slot k)
-  auto sm_piece = [&](const int k) {
-    if (!HAS_PREV) return;
-#ifdef FL_Y_NOSOFTMAX   // experiment: QK waves without the softmax arithmetic (results are garbage)
-    if (k == 9) { pk[0] = pk[1] = pk[2] = pk[3] = 0x38383838; m_new = 0.f; publish(); }
-    return;
-#endif
-    if (k == 0) { load_kl(0); load_kl(1); }
-    else if (k == 1) scale_g(0);
-    else if (k == 2) { scale_g(1); load_kl(2); load_kl(3); }
-    else if (k == 3) scale_g(2);
-    else if (k == 4) scale_g(3);
-    else if (k == 5) ref_piece();
-    else if (k == 6) exp_g(0);
-    else if (k == 7) exp_g(1);
-    else if (k == 8) exp_g(2);
-    else if (k == 9) { exp_g(3); publish(); }
-  };
-  static_assert(kMidSlot == 9, "the P' store is piece 9");
-static_assert(kDmaPerWavePage == 10, "vmcnt(10) in the PV step");
-
-  v16f acc;
-  if (HAS_CUR) {
-    uint4 ka[8][2];
-    int kb0 = lc.kb0;   // opaque per step: the derived k-step offsets are not kept live across steps
-    asm volatile("" : "+v"(kb0));
-    auto k_load = [&](const int s) {
-      ka[s][0] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6)) + (s >> 2) * 256);
-      ka[s][1] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6) ^ 16) + (s >> 2) * 256);
-    };
-    // rope operand of this lane: token 32W + li, 16-B chunk 2s + lh of its 128-B row (stored at chunk ^ ((T>>1)&7))
-    uint4 ra[4];
-    int rb0 = lc.rb0;
-    asm volatile("" : "+v"(rb0));
-#pragma unroll
-    for (int s = 0; s < 4; ++s) ra[s] = *reinterpret_cast<const uint4*>(rp + (rb0 ^ (s << 5)));
-#pragma unroll
-    for (int s = 0; s < 3; ++s) k_load(s);
-    FL_SLOT_END();
-#pragma unroll
-    for (int slot = 0; slot < 12; ++slot) {
-      // (operand reads three k-steps ahead: behind the MFMA of k-step s goes the read of k-step s + 3)
-#ifdef FL_Y_NOQKMFMA   // experiment: QK waves without their MFMA chain (results are garbage)
-      if (slot == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = __uint_as_float(ra[r & 3].x ^ ka[r & 1][0].y);
-      }
-      if (slot >= 4 && slot - 4 + 3 < 8) { k_load(slot - 4 + 3); acc[slot] += __uint_as_float(ka[slot - 4][1].z); }
-#else
-      if (slot == 0) {
-        mfma_rope_first(acc, ra[0], qr[0]);
-      } else if (slot < 4) {
-        mfma_rope(acc, ra[slot], qr[slot]);
-      } else {
-        const int s = slot - 4;
-        mfma_fp8(acc, make_v8i(ka[s][0], ka[s][1]), qn[s]);
-        if (s + 3 < 8) k_load(s + 3);
-      }
-#endif
-      // raw scale of page i+2 (UNCONDITIONAL load: the caller clamps the page into the part — behind a conditional load
-      // hipcc can only wait with vmcnt(0))
-      if (slot == 4) ks_reg = *scale_next;
-      sm_piece(slot);
-      FL_SLOT_END();
-      if (slot == kMidSlot) {
-        FL_T(6);   // chain up to the mid-step barrier || softmax of the previous page
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // P' / reference are in LDS
-        __builtin_amdgcn_s_barrier();   // M_i
-        FL_T(7);   // mid-step barrier
-      }
-    }
-    acc_cur = acc;
-  } else {
-#pragma unroll
-    for (int k = 0; k <= kMidSlot; ++k) {
-      sm_piece(k);
-      FL_SLOT_END();
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // M_i
   }
-  // ---- behind M_i: the two normalisers of page i-1, then the scale triples of page i ----
-#ifdef FL_Y_NOSOFTMAX
-  if (false) {
-#else
-  if (HAS_PREV) {
-#endif
+  FL_T(7);   // MFMA drain + scaling + max
+  const float m_new = tmax > m_w ? ceilf(tmax) + kRefHeadroom : m_w;
+  const float moff = kPShift - m_new;
+  float ev[16];
+  int pk[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) ik4[g] = *reinterpret_cast<const float4*>(scratch + 64 + g * 8 + lh * 4);
+  for (int g = 0; g < 4; ++g) {
+    const float2v a01 = float2v{acc[g * 4 + 0], acc[g * 4 + 1]} + float2v{moff, moff};
+    const float2v a23 = float2v{acc[g * 4 + 2], acc[g * 4 + 3]} + float2v{moff, moff};
+    ev[g * 4 + 0] = __builtin_amdgcn_exp2f(a01[0]);
+    ev[g * 4 + 1] = __builtin_amdgcn_exp2f(a01[1]);
+    ev[g * 4 + 2] = __builtin_amdgcn_exp2f(a23[0]);
+    ev[g * 4 + 3] = __builtin_amdgcn_exp2f(a23[1]);
+    const int v = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 0], ev[g * 4 + 1], 0, false);
+    pk[g] = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 2], ev[g * 4 + 3], v, true);
+  }
+  // publish P' (16 B per lane) and the block reference for the PV waves of this row tile
+  *reinterpret_cast<uint4*>(pbuf_w + lane * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  ref_w[li] = m_new;   // (identical in both lane halves)
+  __builtin_amdgcn_sched_barrier(0);
+  FL_T(10);  // exp + quantise + publish
+  // ---- off the critical path: the two normalisers, then the next page's scale triples ----
+  {
     const float f = __builtin_amdgcn_exp2f(m_w - m_new);   // exactly 1 when the reference did not move
-    // two partial sums each, as packed f32 math
+    // two partial sums each, as PACKED f32 math (v_pk_fma_f32: nothing of this wave runs on the matrix pipe here)
     float2v l2 = {l_run * f, 0.f}, q2 = {lq_run * f, 0.f};
     m_w = m_new;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float2v ik01 = {ik4[g].x, ik4[g].y}, ik23 = {ik4[g].z, ik4[g].w};
       // unrounded sum: exact LSE
-      l2 = __builtin_elementwise_fma(float2v{y_prev[g * 4 + 0], y_prev[g * 4 + 1]}, ik01, l2);
-      l2 = __builtin_elementwise_fma(float2v{y_prev[g * 4 + 2], y_prev[g * 4 + 3]}, ik23, l2);
+      l2 = __builtin_elementwise_fma(float2v{ev[g * 4 + 0], ev[g * 4 + 1]}, ik01, l2);
+      l2 = __builtin_elementwise_fma(float2v{ev[g * 4 + 2], ev[g * 4 + 3]}, ik23, l2);
       // the ROUNDED weights normalise O (numerator and denominator use the same weights: they sum to exactly 1)
       q2 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(pk[g], false), ik01, q2);
       q2 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(pk[g], true), ik23, q2);
@@ -336,7 +254,7 @@ static_assert(kDmaPerWavePage == 10, "vmcnt(10) in the PV step");
     l_run = l2[0] + l2[1];
     lq_run = q2[0] + q2[1];
   }
-  if (HAS_CUR) scale_prep(scratch, ks_cur, tok0w_cur, li, L);   // (behind this wave's last read of page i-1's triples)
+  scale_prep(scratch, ks_next, tok0w + kPage, li, L);
 }
 
 // ---- PV wave: O^T[256 dims x 32 rows] += V^T(page) . P^T, with the LDS-DMA refill of a later page in the MFMA shadow ----
@@ -350,19 +268,27 @@ template <bool DMA>
 __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, const PvLane& lc_in, const int lane,
                                         const uint8_t* __restrict__ vp, const uint8_t* __restrict__ pbuf_rt,
                                         const float* __restrict__ ref_rt, const uint8_t* __restrict__ src_nope,
-                                        uint8_t* __restrict__ dma_dst, const uint8_t* __restrict__ src_rope,
-                                        uint8_t* __restrict__ dma_dst_rope FL_T_PARAMS) {
+                                        uint8_t* __restrict__ dma_dst FL_T_PARAMS) {
   const int li = lane & 31, lh = lane >> 5;
   // opaque copy of the lane constants: nothing derived from them is hoisted out of the page loop (and spilled)
   PvLane lc = lc_in;
-  asm volatile("" : "+v"(lc.vb0), "+v"(lc.dn_row), "+v"(lc.dn_x), "+v"(lc.dr[0]), "+v"(lc.dr[1]));
-  // ---- B_i .. M_i (the QK waves run their MFMA chains): the refill of page i+2 and the first V^T operands ----
-#if !defined(FL_Y_NODMA)
-  if (DMA) dma_page_pieces(lc, src_rope, dma_dst_rope, src_nope, dma_dst);
+  asm volatile("" : "+v"(lc.vb0), "+v"(lc.dn_row), "+v"(lc.dn_x));
+  const uint4 p0 = *reinterpret_cast<const uint4*>(pbuf_rt + lane * 16);
+  const uint4 p1 = *reinterpret_cast<const uint4*>(pbuf_rt + 64 * 16 + lane * 16);
+  const float m0 = ref_rt[li];
+  const float m1 = ref_rt[32 + li];
+  // the refill goes out FIRST: its lead over the page's first reader is what hides the memory latency, and it keeps this
+  // wave's MFMAs out of the QK chain of the SIMD's other wave
+#ifndef FL_Y_DMA_FIRST
+#define FL_Y_DMA_FIRST (FL_Y_MID_BARRIER ? 8 : 0)   // pieces issued before the P' / V^T reads (with the mid-step barrier
+                                                    // this wave has nothing else to do until the QK chains are issued);
+                                                    // the rest goes out one behind each PV MFMA
 #endif
-#ifdef FL_Y_NOCOMPUTE
-  __builtin_amdgcn_s_barrier();   // M_i
-  return;
+#if !defined(FL_Y_NODMA) && !defined(FL_Y_NOPV)
+  if (DMA) {
+#pragma unroll
+    for (int k = 0; k < FL_Y_DMA_FIRST; ++k) fl_dma16_s(src_nope, dn_off(lc, k), dma_dst + k * 1024);
+  }
 #endif
   v8i va[8];
   auto load_vt = [&](int jb) {
@@ -377,27 +303,34 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, con
   load_vt(0);
   load_vt(1);
   load_vt(2);
-  __builtin_amdgcn_sched_barrier(0);
-  FL_T(2);   // refill issue + first V^T reads
-  __builtin_amdgcn_s_barrier();   // M_i: P'(i-1) and its references are in LDS
-  FL_T(6);   // mid-step barrier
-  const uint4 p0 = *reinterpret_cast<const uint4*>(pbuf_rt + lane * 16);
-  const uint4 p1 = *reinterpret_cast<const uint4*>(pbuf_rt + 64 * 16 + lane * 16);
-  const float m0 = ref_rt[li];
-  const float m1 = ref_rt[32 + li];
+#ifdef FL_Y_NOPV   // experiment: PV waves without V^T reads and MFMAs (results are garbage)
+  if (DMA) {
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) fl_dma16_s(src_nope, dn_off(lc, jb), dma_dst + jb * 1024);
+  }
+  m_o = fmaxf(m_o, m0 + m1 + __uint_as_float(p0.x ^ p1.x));
+  return;
+#endif
   const float mw_max = fmaxf(m0, m1);
   m_o = m_o > kNegRef ? m_o : mw_max;
   redo |= (mw_max - m_o > kMaxUp) ? 1 : 0;
   int sb = 127 + (int)fminf((lh ? m1 : m0) - m_o, kMaxUp);
   sb = sb < 0 ? 0 : sb;
   const v8i pb = make_v8i(p0, p1);
+#if FL_Y_MID_BARRIER
+  __builtin_amdgcn_s_barrier();   // M_i: the QK chains are issued
+  FL_T(6);
+#endif
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
     if (jb + 3 < 8) load_vt(jb + 3);
     o[jb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[jb], pb, o[jb], 0, 0, 0, kUnitScale, 0, sb);
+#if !defined(FL_Y_NODMA)
+    if (DMA && jb >= FL_Y_DMA_FIRST) fl_dma16_s(src_nope, dn_off(lc, jb), dma_dst + jb * 1024);
+#endif
   }
   // V^T operand reads three tiles ahead of their MFMA
-  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // P', references
+  if (!FL_Y_MID_BARRIER) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
   for (int jb = 0; jb < 5; ++jb) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -481,10 +414,10 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     {
       // K operand: token T = 32W + li, 32 B at d = 64s + 32lh -> 16-B chunks c = 4s + 2lh + e, stored at chunk c ^ (T&15)
       const int kx = li & 15;
-      lc.rb0 = li * (kDR * 2) + (((lh ^ ((li >> 1) & 7))) << 4);
       lc.kb0 = li * kDN + (((((kx >> 2)) << 2) | ((2 * lh) ^ (kx & 3))) << 4);
     }
     float* scratch = reinterpret_cast<float*>(smem + kOffScratch + w4 * kScratchPerWave);
+    if (FL_Y_QK_PRIO == 2) __builtin_amdgcn_s_setprio(1);
     for (; req < p.bs; ++req, tile_b = 0) {
       FL_Y_REQUEST_HEAD();
       // Q fragments (B operands), once per request
@@ -512,68 +445,64 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       if (!row_ok) L_row = 0;
       const int L_min = p.causal ? L - (p.s_q - 1) : L;
 
-      // raw k_scale of token 32W + li of a page, global -> register two pages ahead.  Every load is UNCONDITIONAL (page
-      // index clamped into the part; an empty part reads the padding page 0): behind a conditional load hipcc can only
-      // wait with vmcnt(0), which would expose the whole latency of the load issued one step earlier, every step.
+      // rope A operand of this lane: token 32W + li, 16-B chunks 2s + lh of its 128-B row; raw scale of token 32W + li.
+      // Every load is UNCONDITIONAL (page index clamped into the part; an empty part reads the padding page 0).
+      auto rope_src = [&](const int t) {
+        return reinterpret_cast<const uint8_t*>(g_k_rope) + (page_of(t) * kPage + 32 * W + li) * (kDR * 2) + lh * 16;
+      };
       auto scale_src = [&](const int t) { return g_k_scale + page_of(t) * kPage + 32 * W + li; };
+      auto load_rope = [&](RopeRegs& r, const int t) {
+        const uint8_t* rp = rope_src(t);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) r.ra[s] = *reinterpret_cast<const uint4*>(rp + s * 32);
+        r.ks = *scale_src(t);
+      };
       for (int pass = 0; pass < 2; ++pass) {
         float l_run = 0.f, lq_run = 0.f, m_w = kNegRef;
-        float ksA, ksB;
-        v16f accA, accB;
+        RopeRegs rA, rB;
         if (pass == 1) load_window(0);
-        ksA = *scale_src(0);
-        ksB = *scale_src(n > 1 ? 1 : 0);
+        load_rope(rA, 0);
+        load_rope(rB, n > 1 ? 1 : 0);
+        scale_prep(scratch, rA.ks, tile_b * kPage + 32 * W, li, L);   // (this wave's reads of the previous request are done)
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // R0: every wave is done with the LDS of the previous request / pass
         FL_T(5);   // request prologue
 
-        // step i: chain of page i into `cur` (rope / scale registers `rr`, refilled with page i+2) || softmax of page
-        // i-1 from `prev`
-#define FL_Y_QK_STEP(HC, HP, MK, RR, CUR, PREV)                                                                         \
-  {                                                                                                                    \
-    if (HC && i + 2 >= win_base + 64 && i + 2 < n) load_window(i + 2); /* pages i+2 .. i+65 */                          \
-    const int t2 = i + 2 < n ? i + 2 : (n > 0 ? n - 1 : 0);                                                            \
-    const float* scale_next = scale_src(t2);                                                                           \
-    FL_T(2); /* loop control */                                                                                        \
-    __builtin_amdgcn_s_barrier(); /* B_i: page i landed */                                                             \
-    FL_T(0); /* barrier */                                                                                             \
-    qk_step<HC, HP, MK>(CUR, PREV, l_run, lq_run, m_w, lc, lane, qn, qr, qs, RR, scale_next,                           \
-                        smem + kOffRing + (i & 3) * kSlotBytes + W * (32 * kDN),                                       \
-                        smem + kOffRope + (i % kRopeSlots) * kRopeBytes + W * (32 * kDR * 2), scratch,                 \
-                        smem + kOffPbuf + (rt * 2 + W) * (64 * 16),                                                    \
-                        reinterpret_cast<float*>(smem + kOffRef) + (rt * 2 + W) * 32,                                  \
-                        (tile_b + i) * kPage + 32 * W, (tile_b + i - 1) * kPage + 32 * W, L, L_row FL_T_ARGS);          \
-    FL_T(1); /* rest of the chain, normalisers, next triples */                                                        \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
-    FL_T(3); /* LDS drain */                                                                                           \
-  }
+        // step i uses `rr` (page i) and refills it with page i+2; `rn` holds page i+1
+        auto step = [&](const int i, RopeRegs& rr, const RopeRegs& rn) {
+          if (i + 2 >= win_base + 64 && i + 2 < n) load_window(i + 2);   // pages i+2 .. i+65
+          const int t2 = i + 2 < n ? i + 2 : n - 1;
+          const uint8_t* rope_next = rope_src(t2);
+          const float* scale_next = scale_src(t2);
+          FL_T(2);   // (loop control)
+          __builtin_amdgcn_s_barrier();   // B_i: page i landed, P buffers of parity i free
+          FL_T(0);   // barrier
+          const int tok0w = (tile_b + i) * kPage + 32 * W;
+          const bool need_mask = (tile_b + i) * kPage + kPage > L_min;
+          qk_step(l_run, lq_run, m_w, lc, lane, qn, qr, qs, rr, rn.ks, rope_next, scale_next,
+                  smem + kOffRing + (i & 3) * kSlotBytes + W * (32 * kDN), scratch,
+                  smem + kOffPbuf + (i & 1) * kPbufPerParity + (rt * 2 + W) * (64 * 16),
+                  reinterpret_cast<float*>(smem + kOffRef + (i & 1) * kRefPerParity) + (rt * 2 + W) * 32, tok0w, L, L_row,
+                  need_mask FL_T_ARGS);
+          FL_T(1);   // softmax tail + publish (issue)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // P', reference published before the next barrier
+          FL_T(3);   // LDS drain
+        };
         {
+          // pairs of steps without a condition in between (a skipped second step would leave a path with nothing issued
+          // behind rA's loads: vmcnt(0) again), then the odd tail
           int i = 0;
-          if (n > 0) {
-            FL_Y_QK_STEP(true, false, false, ksA, accA, accB)
-            // steady state: the softmax page i-1 lies inside every row's limit.  Pairs of steps without a condition in
-            // between (a skipped second step would leave a path with nothing issued behind a rope buffer's loads:
-            // vmcnt(0) again); then the pages around the end of the sequence, one step at a time
-            int n_fast = L_min / kPage - tile_b + 1;   // steps 1 .. n_fast - 1 are unmasked
-            n_fast = n_fast < n ? n_fast : n;
-            for (i = 1; i + 1 < n_fast; i += 2) {
-              FL_Y_QK_STEP(true, true, false, ksB, accB, accA)
-              ++i;
-              FL_Y_QK_STEP(true, true, false, ksA, accA, accB)
-              --i;
-            }
-            for (; i < n; ++i) {
-              if (i & 1) FL_Y_QK_STEP(true, true, true, ksB, accB, accA)
-              else FL_Y_QK_STEP(true, true, true, ksA, accA, accB)
-            }
-            if (n & 1) FL_Y_QK_STEP(false, true, true, ksB, accB, accA)   // i = n: softmax of page n-1 (in accA)
-            else FL_Y_QK_STEP(false, true, true, ksA, accA, accB)         // (in accB)
-          } else {
-            FL_Y_QK_STEP(false, false, false, ksA, accA, accB)
+          for (; i + 1 < n; i += 2) {
+            step(i, rA, rB);
+            step(i + 1, rB, rA);
           }
+          if (i < n) step(i, rA, rB);
         }
-#undef FL_Y_QK_STEP
+        __builtin_amdgcn_s_barrier();   // B_n: the PV waves run PV(n-1)
+#if FL_Y_MID_BARRIER
+        __builtin_amdgcn_s_barrier();   // M_n
+#endif
         // normalisers of this wave's blocks -> LDS for the PV waves' epilogue
         {
           const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -615,11 +544,6 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     // latent DMA piece k of this wave: token row T = (w4*8 + k)*2 + lh, chunk li stored from source chunk li ^ (T&15)
     lc.dn_row = (unsigned)((w4 * kPiecesPerWave * 2 + lh) * kDN);
     lc.dn_x = (unsigned)((li ^ lh) << 4);
-#pragma unroll
-    for (int k = 0; k < kRopePiecesPerWave; ++k) {   // rope piece: 8 token rows of 128 B, chunk c of row T from source chunk c ^ ((T>>1)&7)
-      const int T = (w4 * kRopePiecesPerWave + k) * 8 + (lane >> 3);
-      lc.dr[k] = (unsigned)(T * 128 + (((lane & 7) ^ ((T >> 1) & 7)) << 4));
-    }
   }
   for (; req < p.bs; ++req, tile_b = 0, split_idx = 0) {
     FL_Y_REQUEST_HEAD();
@@ -627,12 +551,11 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const bool is_split = (g_num_splits[req + 1] - split_base) > 1;
     auto ring = [&](int t) { return smem + kOffRing + (t & 3) * kSlotBytes; };
     auto src_of = [&](int t) { return g_k_nope + page_of(t) * (long long)(kPage * kDN); };
-    auto rope_src_of = [&](int t) { return reinterpret_cast<const uint8_t*>(g_k_rope) + page_of(t) * (long long)(kPage * kDR * 2); };
-    auto rope_ring = [&](int t) { return smem + kOffRope + (t % kRopeSlots) * kRopeBytes; };
-    // (issue order per page: rope, latent — kDmaPerWavePage pieces per wave: the counted waits rely on it)
     auto issue_page = [&](int t) {
-      dma_page_pieces(lc, rope_src_of(t), rope_ring(t) + w4 * (kRopePiecesPerWave * 1024), src_of(t),
-                      ring(t) + w4 * (kPiecesPerWave * 1024));
+      const uint8_t* sn = src_of(t);
+      uint8_t* dst = ring(t) + w4 * (kPiecesPerWave * 1024);
+#pragma unroll
+      for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s(sn, dn_off(lc, k), dst + k * 1024);
     };
     const float* lm = reinterpret_cast<const float*>(smem + kOffLm) + rt * 192;
 
@@ -662,7 +585,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
 #define FL_Y_PV_STEP(HAS_PREV, HAS_DMA)                                                                                \
   {                                                                                                                    \
     if (FL_Y_NOWAIT) { /* experiment: timing without the page-landed wait (results are garbage) */                     \
-    } else if (i + 1 < n) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); /* page i landed, page i+1 may stay in flight */ \
+    } else if (i + 1 < n) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* page i landed, page i+1 may stay in flight */ \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
     FL_T(0); /* page-landed wait */                                                                                    \
@@ -670,16 +593,17 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     FL_T(1); /* barrier */                                                                                             \
     if (HAS_DMA && i + 2 >= win_base + 64) load_window(i + 2);                                                         \
     const uint8_t* sn = HAS_DMA ? src_of(i + 2) : nullptr;                                                             \
-    const uint8_t* sr = HAS_DMA ? rope_src_of(i + 2) : nullptr;                                                        \
     uint8_t* dst = ring(i + 2) + w4 * (kPiecesPerWave * 1024);                                                         \
-    uint8_t* dstr = rope_ring(i + 2) + w4 * (kRopePiecesPerWave * 1024);                                               \
     if (HAS_PREV) {                                                                                                    \
       pv_step<HAS_DMA>(o, m_o, redo, lc, lane, ring(i - 1) + W * 256,                                                  \
-                       smem + kOffPbuf + rt * (2 * 64 * 16), reinterpret_cast<const float*>(smem + kOffRef) + rt * 64, \
-                       sn, dst, sr, dstr FL_T_ARGS);                                                                   \
+                       smem + kOffPbuf + ((i - 1) & 1) * kPbufPerParity + rt * (2 * 64 * 16),                          \
+                       reinterpret_cast<const float*>(smem + kOffRef + ((i - 1) & 1) * kRefPerParity) + rt * 64, sn,   \
+                       dst FL_T_ARGS);                                                                                 \
     } else {                                                                                                           \
-      if (HAS_DMA) dma_page_pieces(lc, sr, dstr, sn, dst);                                                             \
-      __builtin_amdgcn_s_barrier(); /* M_i */                                                                          \
+      if (HAS_DMA) {                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s(sn, dn_off(lc, k), dst + k * 1024);      \
+      }                                                                                                                \
+      if (FL_Y_MID_BARRIER) __builtin_amdgcn_s_barrier(); /* M_i */                                                    \
     }                                                                                                                  \
     /* tail of the sequence: zero the rows of page i past the end (P' is exactly 0 there, but 0 * NaN from stale fp8   \
        NaN patterns would poison the PV MFMA of the next step); the QK waves mask those tokens by index */             \
@@ -690,7 +614,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       for (int T = nvalid + 2 * w4 + lh; T < kPage; T += 8)                                                            \
         *reinterpret_cast<uint4*>(wr + T * kDN + li * 16) = make_uint4(0, 0, 0, 0);                                    \
     }                                                                                                                  \
-    FL_T(7); /* PV MFMAs + tail fill */                                                                                \
+    FL_T(2); /* PV + refill issue */                                                                                   \
   }
       {
         int i = 0;
