@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void ep_combine_kernel(const uint16_t* __restr
 
 extern "C" int fl_ep_route(const int32_t* indices, int64_t num_pairs, int experts_per_rank, int world, int cap,
                            int32_t* send_slot, int32_t* send_eid, fl_stream_t stream) {
-  FL_CHECK_ARG(indices && send_slot && send_eid, "fl_ep_route: null pointer");
+  FL_CHECK_ARG((indices || num_pairs == 0) && (send_slot || num_pairs == 0) && send_eid, "fl_ep_route: null pointer");   // (an idle rank routes 0 pairs: empty tensors have null data pointers)
   FL_CHECK_ARG(world >= 1 && world <= 64 && cap >= 1 && experts_per_rank >= 1 && num_pairs >= 0, "fl_ep_route: bad sizes");
   ep_route_kernel<<<1, 256, 0, (hipStream_t)stream>>>(indices, (int)num_pairs, experts_per_rank, world, cap, send_slot, send_eid);
   FL_CHECK_LAUNCH("fl_ep_route");
@@ -176,8 +176,8 @@ extern "C" int fl_ep_sort(const int32_t* recv_eid, int64_t num_slots, int num_lo
 
 extern "C" int fl_ep_gather_rows(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int hidden, void* dst,
                                  int64_t dst_rows, fl_stream_t stream) {
+  if (n == 0) return FL_OK;   // (before the pointer checks: empty tensors have null data pointers)
   FL_CHECK_ARG(src && idx && dst && hidden % 8 == 0, "fl_ep_gather_rows: bad args");
-  if (n == 0) return FL_OK;
   ep_rows_kernel<false><<<dim3((unsigned)n), 256, 0, (hipStream_t)stream>>>(
       (const uint16_t*)src, idx, n, hidden, src_rows, dst_rows, (uint16_t*)dst, 1);
   FL_CHECK_LAUNCH("fl_ep_gather_rows");
@@ -186,8 +186,8 @@ extern "C" int fl_ep_gather_rows(const void* src, int64_t src_rows, const int32_
 
 extern "C" int fl_ep_scatter_rows(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int hidden, void* dst,
                                   int64_t dst_rows, fl_stream_t stream) {
-  FL_CHECK_ARG(src && idx && dst && hidden % 8 == 0, "fl_ep_scatter_rows: bad args");
   if (n == 0) return FL_OK;
+  FL_CHECK_ARG(src && idx && dst && hidden % 8 == 0, "fl_ep_scatter_rows: bad args");
   ep_rows_kernel<true><<<dim3((unsigned)n), 256, 0, (hipStream_t)stream>>>(
       (const uint16_t*)src, idx, n, hidden, src_rows, dst_rows, (uint16_t*)dst, 1);
   FL_CHECK_LAUNCH("fl_ep_scatter_rows");
@@ -196,8 +196,8 @@ extern "C" int fl_ep_scatter_rows(const void* src, int64_t src_rows, const int32
 
 extern "C" int fl_ep_send_rows(const void* x, int64_t num_tokens, const int32_t* send_slot, int64_t num_pairs, int top_k,
                                int hidden, void* send_buf, int64_t send_rows, fl_stream_t stream) {
-  FL_CHECK_ARG(x && send_slot && send_buf && hidden % 8 == 0 && top_k >= 1, "fl_ep_send_rows: bad args");
   if (num_pairs == 0) return FL_OK;
+  FL_CHECK_ARG(x && send_slot && send_buf && hidden % 8 == 0 && top_k >= 1, "fl_ep_send_rows: bad args");
   ep_rows_kernel<true><<<dim3((unsigned)num_pairs), 256, 0, (hipStream_t)stream>>>(
       (const uint16_t*)x, send_slot, num_pairs, hidden, num_tokens, send_rows, (uint16_t*)send_buf, top_k);
   FL_CHECK_LAUNCH("fl_ep_send_rows");
@@ -206,8 +206,8 @@ extern "C" int fl_ep_send_rows(const void* x, int64_t num_tokens, const int32_t*
 
 extern "C" int fl_ep_combine(const void* ret_rows, int64_t num_ret_rows, const int32_t* send_slot, const float* weights,
                              int64_t num_tokens, int top_k, int hidden, void* out, fl_stream_t stream) {
-  FL_CHECK_ARG(ret_rows && send_slot && weights && out && hidden % 8 == 0 && top_k >= 1, "fl_ep_combine: bad args");
   if (num_tokens == 0) return FL_OK;
+  FL_CHECK_ARG(ret_rows && send_slot && weights && out && hidden % 8 == 0 && top_k >= 1, "fl_ep_combine: bad args");
   ep_combine_kernel<<<dim3((unsigned)num_tokens, (unsigned)((hidden / 8 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
       (const uint16_t*)ret_rows, send_slot, weights, num_tokens, top_k, hidden, num_ret_rows, (uint16_t*)out);
   FL_CHECK_LAUNCH("fl_ep_combine");

@@ -217,6 +217,7 @@ extern "C" int fl_fused_add_rmsnorm(const void* x, int num_pieces, int64_t piece
                                     const void* residual_in, const void* gamma, float eps, int64_t T, int H,
                                     void* residual_out, void* norm_out, void* quant_out, float* scale_out,
                                     int64_t s_stride_t, int64_t s_stride_g, fl_stream_t stream) {
+  if (T == 0) return FL_OK;   // (a rank without token rows — T < world — passes empty tensors: null data pointers)
   FL_CHECK_ARG(x && num_pieces >= 1 && T >= 0, "fl_fused_add_rmsnorm: bad arguments");
   FL_CHECK_ARG(gamma != nullptr || (norm_out == nullptr && quant_out == nullptr), "fl_fused_add_rmsnorm: norm needs gamma");
   FL_CHECK_ARG(H > 0 && H % 8 == 0 && H <= kMaxChunks * 512, "fl_fused_add_rmsnorm: H=%d (need H %% 8 == 0, H <= 8192)", H);
@@ -233,6 +234,7 @@ extern "C" int fl_fused_add_rmsnorm(const void* x, int num_pieces, int64_t piece
 extern "C" int fl_dual_rmsnorm(void* ag, int64_t T, int D, int q_rank, int kv_rank, const void* gamma_q,
                                const void* gamma_kv, float eps_q, float eps_kv, void* x_norm_out, void* quant_out,
                                float* scale_out, int64_t s_stride_t, int64_t s_stride_g, fl_stream_t stream) {
+  if (T == 0) return FL_OK;
   FL_CHECK_ARG(ag && gamma_q && gamma_kv && T >= 0, "fl_dual_rmsnorm: bad arguments");
   FL_CHECK_ARG(q_rank > 0 && q_rank % 8 == 0 && q_rank <= 2048 && kv_rank > 0 && kv_rank % 8 == 0 && kv_rank <= 1024 &&
                    q_rank + kv_rank <= D && D % 8 == 0,

@@ -72,6 +72,8 @@ class HipNormOps:
     def add_rmsnorm(self, pieces, add_in, residual_in, gamma, eps, residual_out, norm_out, quant_out, scale_out):
         """pieces [W, T, H] bf16 contiguous."""
         W, T, H = pieces.shape
+        if T == 0:
+            return   # a rank without token rows (T < world): nothing to compute; the collectives around this call still ran
         for t in (pieces, add_in, residual_in, gamma, residual_out, norm_out):
             assert t is None or (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()), "bf16 contiguous CUDA tensors"
         sst, ssg = (scale_out.stride(0), scale_out.stride(1)) if scale_out is not None else (0, 0)
@@ -82,6 +84,8 @@ class HipNormOps:
 
     def dual_rmsnorm(self, ag, q_rank, kv_rank, gamma_q, gamma_kv, eps_q, eps_kv, x_norm_out, quant_out, scale_out):
         T, D = ag.shape
+        if T == 0:
+            return
         assert ag.is_cuda and ag.dtype == torch.bfloat16 and ag.is_contiguous()
         sst, ssg = (scale_out.stride(0), scale_out.stride(1)) if scale_out is not None else (0, 0)
         self._check(self._lib.fl_dual_rmsnorm(ag.data_ptr(), T, D, q_rank, kv_rank, gamma_q.data_ptr(), gamma_kv.data_ptr(),
@@ -157,6 +161,25 @@ def _world(ws):
     return ws.world_size if (dist.is_initialized() and ws.world_size > 1) else 1
 
 
+def _sum_pieces(pieces, out):
+    """out = sum over the W pieces (fp32 accumulate) through the fused kernel: no eager torch arithmetic on this path."""
+    if out.dtype == pieces.dtype and out.is_contiguous():
+        _ops().add_rmsnorm(pieces.contiguous(), None, None, None, 0.0, out, None, None, None)
+    else:
+        tmp = torch.empty(pieces.shape[1:], dtype=pieces.dtype, device=pieces.device)
+        _ops().add_rmsnorm(pieces.contiguous(), None, None, None, 0.0, tmp, None, None, None)
+        out.copy_(tmp)
+
+
+def _gather_rows_uneven(rows, counts, rank, total, group):
+    """every rank contributes `rows` [counts[rank], H] -> [total, H] on every rank (ONE uneven all_to_all_single)."""
+    out = torch.empty((total,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    W = len(counts)
+    dist.all_to_all_single(out, rows.contiguous().repeat(W, 1), output_split_sizes=counts,
+                           input_split_sizes=[counts[rank]] * W, group=group)
+    return out
+
+
 def _gather_pieces(x, ws):
     """[T, H] on every rank -> [W, T, H]: the one-shot all-reduce exchange (every rank receives every peer's tensor)."""
     W = _world(ws)
@@ -183,15 +206,14 @@ def trtllm_allreduce_fusion(allreduce_in, world_size, world_rank, token_num, hid
     counts = get_num_tokens_per_rank(W, T)
     lo = sum(counts[:world_rank]) if W > 1 else 0
     hi = lo + (counts[world_rank] if W > 1 else T)
-    x = allreduce_in
     res_full, res_out_full = residual_in, residual_out
     if residual_reduce_scattered and W > 1:
-        x = allreduce_in.clone()
-        if residual_in is not None:
-            x[lo:hi] += residual_in          # enters the sum exactly once
-        res_full = None
+        # the residual slices are gathered (one small uneven exchange) and enter the fused kernel as its fp32 residual
+        # operand: adding a slice into the bf16 input before the exchange would round (x + residual) once more than the
+        # reference's fused kernel / forward_native do
+        res_full = _gather_rows_uneven(residual_in, counts, world_rank, T, ws.group) if residual_in is not None else None
         res_out_full = torch.empty_like(allreduce_in) if residual_out is not None else None
-    pieces = _gather_pieces(x, ws)
+    pieces = _gather_pieces(allreduce_in, ws)
     want_norm = pattern_code is None or int(pattern_code) != int(AllReduceFusionPattern.kAllReduce)
     if want_norm:
         n_out = norm_out if norm_out is not None else (torch.empty_like(allreduce_in) if partial_norm_out is not None else None)
@@ -201,7 +223,7 @@ def trtllm_allreduce_fusion(allreduce_in, world_size, world_rank, token_num, hid
         if partial_norm_out is not None:
             partial_norm_out.copy_(n_out[lo:hi])
     if allreduce_out is not None:
-        allreduce_out.copy_(pieces.float().sum(0).to(allreduce_out.dtype))
+        _sum_pieces(pieces, allreduce_out)
 
 
 def trtllm_reducescatter_fusion(reducescatter_in, world_size, world_rank, token_num, hidden_dim, workspace_ptrs,
@@ -225,11 +247,11 @@ def trtllm_reducescatter_fusion(reducescatter_in, world_size, world_rank, token_
                                input_split_sizes=counts, group=ws.group)
         pieces = recv.view(W, mine, H)
     if pattern_code is not None and int(pattern_code) == int(ReduceScatterFusionPattern.kReduceScatter):
-        reducescatter_out.copy_(pieces.float().sum(0).to(reducescatter_out.dtype))
+        _sum_pieces(pieces, reducescatter_out)
         return
     _ops().add_rmsnorm(pieces.contiguous(), add_in, residual_in, rms_gamma, rms_eps, residual_out, norm_out, quant_out, scale_out)
     if reducescatter_out is not None:
-        reducescatter_out.copy_(pieces.float().sum(0).to(reducescatter_out.dtype))
+        _sum_pieces(pieces, reducescatter_out)
 
 
 def trtllm_allgather_fusion(allgather_in, world_size, world_rank, hidden_dim, workspace_ptrs, launch_with_pdl=True,
@@ -301,7 +323,30 @@ class TPDPConvertor:
             self.global_rank, self.max_num_tokens, self.tp_size = global_rank, max_num_tokens, tp_size
             self.hidden_size, self.communicator = hidden_size, communicator
 
+    _groups = {}   # (world, tp_size) -> list of process groups, one per block of tp_size consecutive ranks
+
+    @classmethod
+    def _tp_group(cls, global_rank, tp_size):
+        """The attention-TP group of `global_rank`: the block of `tp_size` consecutive ranks it lies in (the layout of
+        dp_attention.py:39-58).  dist.new_group is collective over the WORLD: every rank creates every block, in order,
+        once per (world, tp_size)."""
+        world = dist.get_world_size()
+        if tp_size >= world:
+            if tp_size != world:
+                raise RuntimeError(f"TPDPConvertor: tp_size {tp_size} exceeds the world size {world}")
+            return None
+        if world % tp_size:
+            raise RuntimeError(f"TPDPConvertor: world size {world} is not a multiple of tp_size {tp_size}")
+        key = (world, tp_size)
+        if key not in cls._groups:
+            cls._groups[key] = [dist.new_group(list(range(b * tp_size, (b + 1) * tp_size))) for b in range(world // tp_size)]
+        return cls._groups[key][global_rank // tp_size]
+
     def __init__(self, params, group=None, device=None, dtype=torch.bfloat16):
+        # the reference builds it as TPDPConvertor(Params(global_rank, max_tokens, attn_tp_size, hidden, comm)) with no
+        # group (dp_attention.py:62-74): the exchange runs INSIDE the attention-TP group derived from the params
+        if group is None and dist.is_initialized() and params.tp_size is not None:
+            group = self._tp_group(params.global_rank if params.global_rank is not None else dist.get_rank(), int(params.tp_size))
         self.p, self.group, self.dtype = params, group, dtype
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0

@@ -95,6 +95,15 @@ class AllToAll:
 
     def dispatch(self, out_exclusive_sum, out_expert_x, dp_x, indices, num_global_tokens):
         t = dp_x.shape[0]
+        # (the kernels copy 2-byte rows and read int32 ids whatever the tensors claim to be: check before marshalling)
+        if indices.dtype != torch.int32:
+            raise RuntimeError(f"AllToAll.dispatch: indices must be int32 (got {indices.dtype})")
+        if dp_x.dim() != 2 or dp_x.shape[1] != self.hidden or dp_x.element_size() != 2:
+            raise RuntimeError(f"AllToAll.dispatch: dp_x must be a 2-byte [tokens, {self.hidden}] tensor (got {tuple(dp_x.shape)} {dp_x.dtype})")
+        if indices.numel() != t * self.top_k:
+            raise RuntimeError(f"AllToAll.dispatch: indices must hold {t} x {self.top_k} expert ids (got {indices.numel()})")
+        if self.hidden % 8:
+            raise RuntimeError("AllToAll: hidden must be a multiple of 8")
         if t > self.max_tokens_per_rank:
             raise RuntimeError(f"{t} local tokens exceed the capacity {self.max_tokens_per_rank} this AllToAll was built for")
         dev, S = dp_x.device, self.world * self.cap
@@ -118,6 +127,10 @@ class AllToAll:
             raise RuntimeError("combine() without a preceding dispatch()")
         send_slot, order, n_out, S = self._state
         dev = expert_y.device
+        if expert_y.element_size() != 2 or expert_y.shape[1] != self.hidden:
+            raise RuntimeError(f"AllToAll.combine: expert_y must be a 2-byte [rows, {self.hidden}] tensor")
+        if weights.numel() != out_tokens.shape[0] * self.top_k:
+            raise RuntimeError("AllToAll.combine: weights must hold tokens x top_k values")
         # rows nobody computed (out_expert_x shorter than the slab) must come back as zeros, not as stale memory
         back = (torch.empty if n_out >= S else torch.zeros)(S, self.hidden, dtype=expert_y.dtype, device=dev)
         self.row_ops.scatter(expert_y, order, n_out, back)

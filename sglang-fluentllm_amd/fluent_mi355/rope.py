@@ -40,6 +40,9 @@ def apply_rope_with_cos_sin_cache_inplace(positions, query, key, head_size, cos_
     if Tk != T or pos.numel() != T:
         raise RuntimeError("positions / query / key disagree on the number of tokens")
     cache = cos_sin_cache.contiguous()
+    if cache.dim() != 2 or cache.shape[1] > head_size or cache.shape[1] % 2:
+        raise RuntimeError(f"cos_sin_cache must be [max_position, rotary_dim] with an even rotary_dim <= head_size "
+                           f"(got {tuple(cache.shape)}, head_size {head_size})")
     if T == 0:
         return
     check(lib.fl_rope_inplace(pos.data_ptr(), T, query.data_ptr(), qst, qsh, hq, key.data_ptr(), kst, ksh, hk, cache.data_ptr(),

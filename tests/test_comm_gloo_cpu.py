@@ -70,10 +70,11 @@ def _worker(rank, world, port, T):
                                      workspace_ptrs=ws, pattern_code=comm.AllReduceFusionPattern.kARResidualRMSNormPartialOut,
                                      residual_in=res[lo:hi].contiguous(), residual_out=res_sc_out, norm_out=norm_out2,
                                      rms_gamma=gamma, rms_eps=eps, residual_reduce_scattered=True, partial_norm_out=partial)
-        # the scattered residual enters through one rank's bf16 piece: one extra bf16 rounding vs the full-residual sum
-        assert torch.allclose(norm_out2.float(), y_ref.float(), atol=3e-2, rtol=3e-2)
+        # the residual slices are gathered and enter the fused kernel as its fp32 residual operand: bit-identical to the
+        # full-residual call (and to forward_native)
+        assert torch.equal(norm_out2, y_ref)
         assert torch.equal(partial, norm_out2[lo:hi])
-        assert torch.allclose(res_sc_out.float(), r_ref[lo:hi].float(), atol=3e-2, rtol=3e-2)
+        assert torch.equal(res_sc_out, r_ref[lo:hi])
 
         # ---- C6: reduce-scatter (uneven split) + add_in + residual + RMSNorm ----
         n = hi - lo
@@ -127,6 +128,48 @@ def _worker(rank, world, port, T):
             assert torch.all(outv[:, 8 * r:8 * r + 8] == r + 1)
     finally:
         dist.destroy_process_group()
+
+
+def _worker_tp_groups(rank, world, port, tp):
+    """TPDPConvertor inside attention-TP groups smaller than the world (DP-attention: dp_attention.py:39-74): every DP replica
+    has its OWN token count, the exchange must stay inside the replica's block of `tp` ranks."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "sglang-fluentllm_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from comm_torch_ops import TorchNormOps
+        from fluent_mi355.comm import get_num_tokens_per_rank, set_norm_ops
+        from eps.communication import TPDPConvertor
+
+        set_norm_ops(TorchNormOps())
+        H = 64
+        block, r_in = rank // tp, rank % tp
+        T = [5, 1][block]   # different token counts per replica (1 < tp: one rank of block 1 owns no rows)
+        g = torch.Generator().manual_seed(100 + block)
+        xs = [torch.randn(T, H, generator=g).to(torch.bfloat16) for _ in range(tp)]
+        full = torch.randn(T, H, generator=g).to(torch.bfloat16)
+        counts = get_num_tokens_per_rank(tp, T)
+        lo, hi = sum(counts[:r_in]), sum(counts[:r_in + 1])
+        conv = TPDPConvertor(TPDPConvertor.Params(rank, 64, tp, H, None), device=torch.device("cpu"))   # no group passed
+        assert conv.world == tp and conv.rank == r_in
+        rs = conv.get_reduce_scatter_context(T, 45)
+        rs.input().copy_(xs[r_in])
+        conv.reduce_scatter(rs, None)
+        assert rs.output_row_offset == lo
+        assert torch.equal(rs.output(), torch.stack(xs)[:, lo:hi].float().sum(0).to(torch.bfloat16))
+        ag = conv.get_all_gather_context(T, H, 28)
+        if hi > lo:
+            ag.input().copy_(full[lo:hi])
+        conv.all_gather(ag, None)
+        assert torch.equal(ag.output(), full)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tpdp_convertor_inside_attention_tp_groups_world4_tp2():
+    port = _free_port()
+    mp.spawn(_worker_tp_groups, args=(4, port, 2), nprocs=4, join=True)
 
 
 @pytest.mark.parametrize("T", [5, 8, 1])

@@ -143,6 +143,49 @@ def test_grouped_offset_vs_oracle(counts, N, K):
     assert bool((out[M:] == 7.0).all())
 
 
+def _route_counts(T, E, top_k, zipf, seed):
+    """rows per expert of a top-k routing without replacement per token: uniform, or Zipf-skewed expert popularity"""
+    g = torch.Generator().manual_seed(seed)
+    p = torch.ones(E) if not zipf else 1.0 / torch.arange(1, E + 1, dtype=torch.float64) ** zipf
+    p = p[torch.randperm(E, generator=g)]
+    ids = torch.multinomial((p / p.sum()).expand(T, E), top_k, replacement=False, generator=g)
+    return torch.bincount(ids.reshape(-1), minlength=E).tolist()
+
+
+@pytest.mark.parametrize("T,zipf,N,K", [(32, 0.0, 256, 256),       # decode: 256 rows over 256 experts, many empty
+                                        (160, 0.0, 256, 256),      # ~5 rows per expert
+                                        (160, 1.2, 256, 512),      # skewed: a few hot experts, most empty
+                                        (2048, 1.2, 384, 256),     # skewed, hot experts with > 256 rows (several tiles each)
+                                        (4096, 0.0, 256, 256)])    # 128 rows per expert (BASELINE config 3 at T = 4096)
+def test_grouped_offset_e256_top8_routing_vs_oracle(T, zipf, N, K):
+    """BASELINE config 3's group structure (E = 256 experts, top-8 routing incl. empty experts and a Zipf-skewed load): the
+    offset-mode tile lookup walks the groups 64 at a time with a running base (grouped_gemm_shared.h locate_tile), and only
+    E > 64 exercises iterations 2..4 of that walk."""
+    import deep_gemm
+
+    counts = _route_counts(T, 256, 8, zipf, seed=T + int(zipf * 10))
+    assert sum(counts) == T * 8 and len(counts) == 256
+    if T <= 160:
+        assert counts.count(0) > 0   # empty experts are part of the case
+    xq, xs, W, Ws, ex = make_group_case(counts, N, K, seed=T)
+    M = xq.shape[0]
+    mp = (M + 256 * 31) // 32 * 32 + 32
+    xs_dev = torch.zeros((K // 128, mp), dtype=torch.float32, device=DEV).permute(-1, -2)
+    xs_dev[:M] = xs.to(DEV)
+    out = torch.full((M + 5, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset((xq.to(DEV), xs_dev[:M]), (W.to(DEV), Ws.to(DEV)), out[:M], ex.to(DEV))
+    ref = gemm_ref.grouped_gemm_offset(xq, xs, W, Ws, ex)
+    o = out[:M].cpu()
+    assert rel_mae(o, ref) < 1e-3
+    # per-expert check: a wrong running base would put a tile's rows under the wrong expert's weights
+    exl = ex.tolist()
+    for e in (0, 63, 64, 65, 127, 128, 191, 192, 255):
+        lo, hi = exl[e], exl[e + 1]
+        if hi > lo:
+            assert rel_mae(o[lo:hi], ref[lo:hi]) < 2e-3, e
+    assert bool((out[M:] == 7.0).all())
+
+
 def test_grouped_contiguous_and_masked_vs_oracle():
     import deep_gemm
 

@@ -106,16 +106,24 @@ def run_decode(fm, c, H, s_q=1, causal=True, emulate=True):
     return o.cpu(), lse.cpu(), ref, rlse, ns.cpu()
 
 
+MEASURED = []   # (tag, rel-MAE, max-abs, max|ref|, max LSE error): written out by test_zz_write_measured_errors
+
+
 def check(o, lse, ref, rlse, tag):
     assert torch.isfinite(o.float()).all(), tag
     err = (o.double() - ref).abs()
     rel = float(err.mean() / ref.abs().mean().clamp_min(1e-30))
-    # stated FP8 tolerance vs dequantise-then-exact attention: rel-MAE < 3e-2, max-abs < 1e-1 on N(0,1)-scaled data
-    # (|o| <= ~4; for larger outputs the absolute bound scales with the data: 2.5e-2 of max|o|).  Why 3e-2: P is
-    # re-quantised to e4m3 (3 mantissa bits, rms relative rounding 2^-4/sqrt(3) = 3.6 % per weight); on i.i.d. V rows
-    # signal and rounding noise both scale as 1/sqrt(N_eff), so rel-MAE sits at ~2 % for every length (CPU emulation:
-    # 1.8-2.4e-2 for L = 64..1024).  The bit-level statement of the kernel is checked to 3e-3 in run_decode.
-    assert rel < 3e-2, (tag, rel)
+    _fin = torch.isfinite(rlse)
+    MEASURED.append({"case": str(tag), "rel_mae": rel, "max_abs": float(err.max()), "max_ref": float(ref.abs().max()),
+                     "lse_err": float((lse.double()[_fin] - rlse[_fin]).abs().max()) if bool(_fin.any()) else 0.0})
+    # stated FP8 tolerance vs dequantise-then-exact attention: rel-MAE < 2.7e-2 = 1.25 x the worst MEASURED case (2.15e-2 over
+    # the 30 cases of this file incl. the full-size ones: profiles/r02_mla_parity_measured.json), max-abs < 1e-1 on
+    # N(0,1)-scaled data (|o| <= ~4; for larger outputs the absolute bound scales with the data).  SURVEY section 8c's 2e-2
+    # is what exact P would give; here P is re-quantised to e4m3 for the MX PV MFMA (3 mantissa bits, rms relative rounding
+    # 2^-4/sqrt(3) = 3.6 % per weight): on i.i.d. V rows signal and rounding noise both scale as 1/sqrt(N_eff), so rel-MAE
+    # sits at 1.7-2.2e-2 for every length (the CPU emulation of the kernel's arithmetic reproduces it to three digits).
+    # The bit-level statement of the kernel is checked to 3e-3 in run_decode.
+    assert rel < 2.7e-2, (tag, rel)
     # max-abs: 1e-1 on N(0,1) data for ordinary lengths; 2-3-token sequences are the worst case of fp8 weights: the weight
     # ratio moves by <= 2*2^-4*w1*w2 <= 3.1e-2, times |v1-v2| <= 2 max|v|  ->  bound 5e-2 * max|o| covers it
     assert float(err.max()) < max(1e-1, 5e-2 * float(ref.abs().max())), (tag, float(err.max()))
@@ -216,23 +224,28 @@ def test_decode_vs_reference_backend_golden(fm):
         assert float((o.cpu().float() - ref.float()).abs().max()) < 2e-1, name
 
 
-def test_full_size_properties_bs128_seq4096(fm):
-    """BASELINE config 2 at full size: the oracle is too slow here, so check size-independent properties:
-    (1) o is a convex combination of V rows: |o| <= max|V| per dim; (2) permuting pages (same logical content)
-    leaves the output bit-identical; (3) a sampled subset of requests matches the oracle."""
-    torch.manual_seed(0)
-    bs, L, H = 128, 4096, 128
-    npg = L // 64
-    pages = bs * npg + 1
-    g = torch.Generator(device="cuda").manual_seed(0)
+def _full_size_properties(fm, lens, H, samples, tag):
+    """Full-size checks where the oracle is too slow for the whole batch — size-independent properties:
+    (1) o is a convex combination of V rows: |o| <= max|V|; (2) moving every page to another physical location (same
+    logical content) leaves the output BIT-identical; (3) a sampled subset of requests matches the oracle."""
+    bs = len(lens)
+    npgs = [(L + 63) // 64 for L in lens]
+    mp, pages = max(npgs), sum(npgs) + 1
+    g = torch.Generator(device="cuda").manual_seed(len(lens) + H)
     key = torch.randn(pages * 64, 1, 576, device=dev(), generator=g, dtype=torch.float32).to(torch.bfloat16)
     k_lora = torch.empty(pages * 64, 1, 512, dtype=torch.uint8, device=dev())
     k_scale = torch.empty(pages * 64, 1, 1, dtype=torch.float32, device=dev())
     k_rope = torch.empty(pages * 64, 1, 64, dtype=torch.bfloat16, device=dev())
     fm.quantize_and_cache_k(key, k_lora, k_scale, k_rope, torch.arange(pages * 64, dtype=torch.int32, device=dev()), 512)
-    perm = torch.randperm(pages - 1, device=dev(), generator=g).to(torch.int32) + 1
-    bt = perm.view(bs, npg).contiguous()
-    seq = torch.full((bs,), L, dtype=torch.int32, device=dev())
+    del key
+    perm = (torch.randperm(pages - 1, device=dev(), generator=g).to(torch.int32) + 1).cpu()
+    bt = torch.zeros(bs, mp, dtype=torch.int32)          # unused tail entries point at the padding page 0
+    o0 = 0
+    for b, n in enumerate(npgs):
+        bt[b, :n] = perm[o0:o0 + n]
+        o0 += n
+    bt = bt.to(dev())
+    seq = torch.tensor(lens, dtype=torch.int32, device=dev())
     q = torch.randn(bs, 1, H, 576, device=dev(), generator=g, dtype=torch.float32).to(torch.bfloat16)
     qn, qs, qr = fm.quantize_ckv_per_token_head(q, 512)
     meta, ns = fm.get_mla_metadata(seq, H, 1)
@@ -242,24 +255,45 @@ def test_full_size_properties_bs128_seq4096(fm):
                                               ks.view(pages, 64, 1, 1), table, seq, 512, meta, ns, SCALE, True)
 
     o, lse = run(k_lora, k_scale, k_rope, bt)
-    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all(), tag
     vmax = (k_lora.view(torch.float8_e4m3fn).float() * k_scale).abs().amax()
-    assert float(o.float().abs().max()) <= float(vmax) * 1.01
-    # (2) physical page permutation invariance (bit-exact): move every page to a new physical location
+    assert float(o.float().abs().max()) <= float(vmax) * 1.01, tag
+    # (2) physical page permutation invariance (bit-exact)
     perm2 = torch.randperm(pages - 1, device=dev(), generator=g) + 1
     inv = torch.zeros(pages, dtype=torch.long, device=dev())
-    inv[1:] = perm2                                           # old page p -> new page inv[p]
+    inv[1:] = perm2                                           # old page p -> new page inv[p]; page 0 stays
     kl2, ks2, kr2 = torch.empty_like(k_lora), torch.empty_like(k_scale), torch.empty_like(k_rope)
     for src, dst in ((k_lora, kl2), (k_scale, ks2), (k_rope, kr2)):
         dst.view(pages, -1)[inv] = src.view(pages, -1)
     o2, lse2 = run(kl2, ks2, kr2, inv[bt.long()].to(torch.int32).contiguous())
-    assert torch.equal(o.view(torch.int16), o2.view(torch.int16)) and torch.equal(lse, lse2)
+    assert torch.equal(o.view(torch.int16), o2.view(torch.int16)) and torch.equal(lse, lse2), tag
+    del kl2, ks2, kr2
     # (3) sampled requests vs oracle
-    for b in (0, 77, 127):
-        ref, rlse = mla_ref.mla_decode_fp8_per_token(qn[b:b + 1].cpu(), qs[b:b + 1].cpu(), qr[b:b + 1].cpu(),
-                                                     k_lora.cpu().view(pages, 64, 1, 512), k_scale.cpu().view(pages, 64, 1, 1),
-                                                     k_rope.cpu().view(pages, 64, 1, 64), bt[b:b + 1].cpu(), seq[b:b + 1].cpu(), SCALE, True)
-        check(o[b:b + 1].cpu(), lse[b:b + 1].cpu(), ref, rlse, f"full-size req {b}")
+    kl_c, ks_c, kr_c = k_lora.cpu().view(pages, 64, 1, 512), k_scale.cpu().view(pages, 64, 1, 1), k_rope.cpu().view(pages, 64, 1, 64)
+    for b in samples:
+        ref, rlse = mla_ref.mla_decode_fp8_per_token(qn[b:b + 1].cpu(), qs[b:b + 1].cpu(), qr[b:b + 1].cpu(), kl_c, ks_c, kr_c,
+                                                     bt[b:b + 1].cpu(), seq[b:b + 1].cpu(), SCALE, True)
+        check(o[b:b + 1].cpu(), lse[b:b + 1].cpu(), ref, rlse, f"{tag} req {b} (len {lens[b]})")
+
+
+def test_full_size_properties_bs128_seq4096(fm):
+    """BASELINE config 2 at full size (bs=128, seq=4096, H=128)."""
+    _full_size_properties(fm, [4096] * 128, 128, (0, 77, 127), "cfg2")
+
+
+def test_full_size_properties_cfg2_ragged(fm):
+    """BASELINE config 2, ragged variant: lengths uniform in 2048..6144 (mean 4096), page edges included."""
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(2048, 6145, (128,), generator=g).tolist()
+    lens[3], lens[90] = 2048, 6144
+    lens[17] = 4097                      # one token on its last page
+    _full_size_properties(fm, lens, 128, (3, 17, 90, 127), "cfg2-ragged")
+
+
+def test_full_size_properties_cfg4_shape(fm):
+    """BASELINE config 4's attention shape on one rank of attention-TP8: 16 heads per GPU, bs=256, seq=8192 (every rank
+    streams all requests' latent KV)."""
+    _full_size_properties(fm, [8192] * 256, 16, (0, 131, 255), "cfg4-H16")
 
 
 def test_graph_capture_replay(fm):
@@ -556,3 +590,21 @@ def test_quant_divisions_bit_exact_on_adversarial_rows(fm):
     rn, rs, rr = mla_ref.quantize_ckv_per_token_head(q, 512)
     assert torch.equal(qn.cpu().view(torch.uint8), rn.view(torch.uint8)) and torch.equal(qs.cpu(), rs)
     assert torch.equal(qr.cpu().view(torch.int16), rr.view(torch.int16))
+
+
+def test_zz_write_measured_errors():
+    """Not a check: dumps the per-case measured errors of this run (rel-MAE, max-abs, LSE) so that the stated tolerances
+    can be read against what the kernel actually does (profiles/r02_mla_parity_measured.json is a committed copy)."""
+    import json
+    import os
+
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "mla_parity_measured.json"), "w") as f:
+            json.dump(MEASURED, f, indent=1)
+    except OSError:
+        pass
+    if MEASURED:
+        worst = max(MEASURED, key=lambda m: m["rel_mae"])
+        print(f"\nK1 measured over {len(MEASURED)} cases: worst rel-MAE {worst['rel_mae']:.4f} ({worst['case']})")
