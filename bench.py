@@ -72,45 +72,126 @@ def layer_call(fm, wl, l, meta, ns):
                                           SCALE, True)
 
 
-def cpu_baseline(threads_cap=None):
-    """The reference's CPU path for this op (torch_native_backend.py:309-343) as restated in oracle/mla_ref.py,
-    bf16 KV, same shape per request (H=128, seq=4096), bounded sample of requests."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _physical_cores():
+    """physical cores visible to this process (SMT siblings counted once)"""
+    try:
+        cores = set()
+        allowed = os.sched_getaffinity(0)
+        for c in allowed:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                cores.add(f.read().strip())
+        return max(1, len(cores))
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(budget_s=28.0):
+    """The reference's CPU path for this op (TorchNativeAttnBackend.forward_decode, torch_native_backend.py:309-343) as
+    restated in oracle/mla_ref.py, bf16 KV, on ALL physical cores of the box (SURVEY section 8d / BASELINE.md section 3):
+    2 warm-ups, then the median of >= 5 runs, (a) at BASELINE config 1 (bs=1, H=16, seq=128) and (b) at config 2's shape per
+    request (H=128, seq=4096) on a reduced batch (stated), scaled to tokens/s of the 61-layer decode step."""
     from oracle import mla_ref
 
-    ncores = os.cpu_count() or 1
+    ncores = _physical_cores()
+    torch.set_num_threads(ncores)
     g = torch.Generator().manual_seed(0)
-    bs_s = 2
-    npg = SEQ // 64
-    slots = (bs_s * npg + 1) * 64
-    kv = torch.randn(slots, 1, 576, generator=g).to(torch.bfloat16)
-    perm = torch.randperm(bs_s * npg, generator=g) + 1
-    r2t = (perm.view(bs_s, npg, 1) * 64 + torch.arange(64).view(1, 1, 64)).view(bs_s, -1).to(torch.int32)
-    q = torch.randn(bs_s, H, 576, generator=g).to(torch.bfloat16)
-    seq = torch.full((bs_s,), SEQ, dtype=torch.int64)
-    args = (q, kv, r2t, torch.arange(bs_s), seq, SCALE)
-    # the per-request SDPA is small: more threads than ~a socket's worth only adds synchronisation; take the best of a
-    # short sweep (fair to the CPU) and report the thread count actually used
-    best = None
-    t_all = time.perf_counter()
-    for nthreads in [c for c in (16, 32, 64, ncores) if c <= ncores]:
-        if threads_cap and nthreads > threads_cap:
-            continue
-        torch.set_num_threads(nthreads)
-        mla_ref.torch_native_decode(*args)  # warm-up
+
+    def case(bs_s, h, seq):
+        npg = (seq + 63) // 64
+        slots = (bs_s * npg + 1) * 64
+        kv = torch.randn(slots, 1, 576, generator=g).to(torch.bfloat16)
+        perm = torch.randperm(bs_s * npg, generator=g) + 1
+        r2t = (perm.view(bs_s, npg, 1) * 64 + torch.arange(64).view(1, 1, 64)).view(bs_s, -1).to(torch.int32)
+        q = torch.randn(bs_s, h, 576, generator=g).to(torch.bfloat16)
+        return (q, kv, r2t, torch.arange(bs_s), torch.full((bs_s,), seq, dtype=torch.int64), SCALE)
+
+    def median_time(args, budget):
+        t_all = time.perf_counter()
+        for _ in range(2):
+            mla_ref.torch_native_decode(*args)
         times = []
-        while len(times) < 3 and (time.perf_counter() - t_all) < 28.0:
+        while len(times) < 5 or (len(times) < 9 and time.perf_counter() - t_all < budget):
             t0 = time.perf_counter()
             mla_ref.torch_native_decode(*args)
             times.append(time.perf_counter() - t0)
-        if times and (best is None or sorted(times)[len(times) // 2] < best[0]):
-            best = (sorted(times)[len(times) // 2], nthreads, len(times))
-    t, nthreads, ntimes = best
-    times = [t] * ntimes
-    per_req_layer = t / bs_s
-    return {"value": 1.0 / (per_req_layer * LAYERS), "unit": "tokens/s", "cores": nthreads, "kind": "port",
+        return sorted(times)[len(times) // 2], len(times)
+
+    t1, n1 = median_time(case(1, 16, 128), 2.0)
+    bs_s = 2
+    t2, n2 = median_time(case(bs_s, H, SEQ), budget_s)
+    per_req_layer = t2 / bs_s
+    return {"value": round(1.0 / (per_req_layer * LAYERS), 4), "unit": "tokens/s", "cores": ncores, "kind": "port",
+            "cpu_model": _cpu_model(), "cfg1_ms_per_layer_call": round(t1 * 1e3, 3),
             "sample": f"oracle.mla_ref.torch_native_decode (reference torch_native_backend.py:309-343 restated), bf16 KV, "
-                      f"bs={bs_s} of 128, H={H}, seq={SEQ}, median of {len(times)} layer-calls, {per_req_layer*1e3:.1f} ms per "
-                      f"request-layer, x{LAYERS} layers"}
+                      f"torch.set_num_threads({ncores}) = all physical cores; config 2 shape at bs={bs_s} of 128 (H={H}, seq={SEQ}): "
+                      f"median of {n2} layer-calls after 2 warm-ups = {per_req_layer * 1e3:.1f} ms per request-layer, x{LAYERS} "
+                      f"layers -> tokens/s; config 1 (bs=1, H=16, seq=128): median of {n1} = {t1 * 1e3:.3f} ms per layer-call"}
+
+
+def gemm_roofline(dev):
+    """BASELINE config 3 (north_star's second half): DeepSeek-V3 MoE w13 grouped GEMM [rows, 7168] x [256 experts, 4096, 7168],
+    FP8 block-scaled, top-8 routing, TP=1 — fp8 MFMA fraction in the compute regime (T = 16384 tokens, 512 rows per expert)
+    and the weight-stream HBM fraction in the decode regime (T = 128).  HIP events on the launch stream."""
+    import deep_gemm
+
+    HID, INTER, E, TOPK = 7168, 2048, 256, 8
+    g = torch.Generator(device=dev).manual_seed(0)
+    w = torch.empty(E, 2 * INTER, HID, dtype=torch.float8_e4m3fn, device=dev)
+    flat = w.view(-1).view(torch.uint8)
+    step = 1 << 28
+    for i in range(0, flat.numel(), step):   # random bytes avoiding the NaN patterns 0x7f / 0xff
+        n = min(step, flat.numel() - i)
+        b = torch.randint(0, 255, (n,), device=dev, generator=g, dtype=torch.int16)
+        flat[i:i + n] = torch.where((b & 0x7F) == 0x7F, b - 1, b).to(torch.uint8)
+    ws = torch.rand(E, 2 * INTER // 128, HID // 128, device=dev, generator=g) * 1e-2
+    res = {"workload": "w13 grouped GEMM, 256 experts top-8 uniform routing, hidden 7168, 2 x inter 4096, fp8 e4m3 1x128 / 128x128 block scales"}
+    for T, iters in ((16384, 3), (128, 20)):
+        M = T * TOPK
+        ids = torch.stack([torch.randperm(E, device=dev, generator=g)[:TOPK] for _ in range(min(T, 2048))])
+        ids = ids.repeat((T + ids.shape[0] - 1) // ids.shape[0], 1)[:T].reshape(-1)
+        counts = torch.bincount(ids, minlength=E)
+        ex = torch.zeros(E + 1, dtype=torch.int32, device=dev)
+        ex[1:] = torch.cumsum(counts, 0)
+        mp = (M + E * 31) // 32 * 32
+        xq = (torch.randn(M, HID, device=dev, generator=g) / 10).to(torch.float8_e4m3fn)
+        xs = (torch.rand((HID // 128, mp), device=dev, generator=g) * 1e-2 + 1e-3).permute(-1, -2)
+        out = torch.empty(M, 2 * INTER, dtype=torch.bfloat16, device=dev)
+
+        def run():
+            deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset((xq, xs[:M]), (w, ws), out, ex, use_pdl=True)
+
+        run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / iters
+        flops = 2.0 * M * 2 * INTER * HID
+        hit = int((counts > 0).sum())
+        byts = hit * (2 * INTER * HID) + M * (HID + HID // 128 * 4) + M * 2 * INTER * 2
+        res[f"T{T}"] = {"ms": round(t * 1e3, 3), "TFLOPs": round(flops / t / 1e12, 1),
+                        "mfma_frac": round(flops / t / 1e12 / 5000.0, 4), "GBs": round(byts / t / 1e9, 1),
+                        "hbm_frac": round(byts / t / 1e9 / HBM_PEAK_GBS, 4), "rows_per_expert": round(M / E, 1)}
+        del xq, xs, out
+    res["mfma_frac"] = res["T16384"]["mfma_frac"]          # of the 5 PFLOP/s dense fp8 peak
+    res["T128_hbm_frac"] = res["T128"]["hbm_frac"]         # weight stream, of 8 TB/s
+    del w, ws
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -121,6 +202,7 @@ def main():
     ap.add_argument("--layers", type=int, default=LAYERS, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-gemm", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -231,19 +313,29 @@ def main():
         per_launch_s = e0.elapsed_time(e1) * 1e-3 / (reps * layers)
         alg = algorithmic_bytes(BS, SEQ, H, S_Q)
         achieved = alg / per_launch_s / 1e9
-        traffic = None   # HBM bytes per launch from the committed PMC passes of this kernel/workload (not re-measured here)
+        # HBM bytes per launch: NOT measured in this run — read from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 +
+        # WRITE_SIZE, MI355X_MICROARCH.md) of the kernel this build dispatches at this workload; the source file is named
+        traffic, traffic_src = None, None
+        y_on = os.environ.get("FLUENT_MLA_Y") != "0"
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic_src = "profiles/r02_pmc_traffic.json" if y_on else "profiles/r01_pmc_traffic.json"
+            with open(os.path.join(ROOT, traffic_src)) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch"])
         except Exception:
-            pass
+            traffic_src = None
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": ("mla_decode_x_kernel" if (H * S_Q > 64 and os.environ.get("FLUENT_MLA_X") != "0")
-                           else "mla_decode_fp8_kernel") + "(+mla_combine_kernel)",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": ("mla_decode_y_kernel" if (y_on and H * S_Q > 32) else
+                           "mla_decode_x_kernel" if (H * S_Q > 64 and os.environ.get("FLUENT_MLA_X") != "0")
+                           else "mla_decode_fp8_kernel") + " (+ mla_combine_kernel: early exit, nothing is split at this shape)",
                 "us_per_launch": round(per_launch_s * 1e6, 2),
                 "algorithmic_bytes_per_launch": alg}
     cpu = None
+    gemm = None
+    if rank == 0 and world == 1 and not a.no_gemm:
+        del wl
+        torch.cuda.empty_cache()
+        gemm = gemm_roofline(dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
@@ -256,7 +348,7 @@ def main():
                                    "pages randomly permuted, K3 metadata once + 61 layers x (K5 store + K4 quant-q + K1 decode) per step",
                        "bs_per_gpu": BS, "seq_len": SEQ, "heads": H, "layers_per_step": layers,
                        "parallelism": f"dp{world} (DP-attention, no data-path collective)", "hipgraph": graph is not None},
-            "roofline": roof, "cpu_baseline": cpu}))
+            "roofline": roof, "gemm": gemm, "cpu_baseline": cpu}))
     if dist is not None:
         dist.destroy_process_group()
 
