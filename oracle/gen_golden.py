@@ -354,8 +354,103 @@ def gen_ep_scatter_gather():
     print("ep_scatter_gather", T, H, K, E, M, start.tolist())
 
 
+def gen_call_trace():
+    """Call-trace fixture of the boundary: FlashMLABackend.forward_decode and the verify branch of forward_extend
+    (flashmla_backend.py:88-256) are exec'd FROM THE REFERENCE SOURCE (their module does not import under stubs) against
+    recording fakes of `flash_mla_fp8` / `flash_mla_swap`; what they pass — function, keyword names, shapes, dtypes,
+    strides, scalars, and the view taken of the result — is written to tests/golden/flashmla_backend_call_trace.json.
+    The GPU test replays every recorded call through the real modules."""
+    import json
+    import types
+
+    from sglang.srt.model_executor.forward_batch_info import ForwardMode
+
+    path = os.path.join(_ref_import.REF_ROOT, "sglang/srt/layers/attention/flashmla_backend.py")
+    calls = []
+
+    def describe(v):
+        if torch.is_tensor(v):
+            return {"tensor": True, "shape": list(v.shape), "dtype": str(v.dtype).replace("torch.", ""),
+                    "stride": list(v.stride()), "contiguous": bool(v.is_contiguous())}
+        if isinstance(v, (bool, int, float)) or v is None:
+            return {"value": v}
+        return {"repr": repr(v)}
+
+    class Recorder(types.SimpleNamespace):
+        def __init__(self, name):
+            super().__init__()
+            self._name = name
+
+        def quantize_ckv_per_token_head(self, q, kv_lora_rank):
+            calls.append({"module": self._name, "fn": "quantize_ckv_per_token_head", "args": [describe(q), describe(kv_lora_rank)], "kwargs": {}})
+            lead = q.shape[:-1]
+            return (torch.zeros(lead + (kv_lora_rank,), dtype=torch.float8_e4m3fn), torch.ones(lead + (1,), dtype=torch.float32),
+                    torch.zeros(lead + (q.shape[-1] - kv_lora_rank,), dtype=torch.bfloat16))
+
+        def _attend(self, fn, q_like, kw):
+            calls.append({"module": self._name, "fn": fn, "args": [], "kwargs": {k: describe(v) for k, v in kw.items()}})
+            bs, s_q, h = q_like.shape[:3]
+            return torch.zeros(bs, s_q, h, kw["head_dim_v"], dtype=torch.bfloat16), torch.zeros(bs, h, s_q, dtype=torch.float32)
+
+        def flash_mla_ckv_fp8_per_token(self, **kw):
+            return self._attend("flash_mla_ckv_fp8_per_token", kw["q_nope"], kw)
+
+        def flash_mla_with_kvcache(self, **kw):
+            return self._attend("flash_mla_with_kvcache", kw["q"], kw)
+
+    fp8_mod, swap_mod = Recorder("flash_mla_fp8"), Recorder("flash_mla_swap")
+    ns = {"torch": torch, "PAGE_SIZE": 64, "ForwardMode": ForwardMode, "flash_mla_fp8": fp8_mod, "flash_mla_swap": swap_mod,
+          "RadixAttention": object, "ForwardBatch": object, "Optional": __import__("typing").Optional}
+    _ref_import.load_functions_from_source(path, {"get_flash_mla_module"}, ns)
+    module_fn = ns["get_flash_mla_module"]
+    forward_decode = _ref_import.load_method_from_source(path, "FlashMLABackend", "forward_decode", ns)
+    forward_extend = _ref_import.load_method_from_source(path, "FlashMLABackend", "forward_extend", ns)
+    # (FlashMLABackend.get_flash_mla_module, :85-86, is `return get_flash_mla_module(M, self.cache_quant_method)`: bound below
+    #  by hand — exec'd next to the module-level function of the same name it would shadow it)
+
+    def run(tag, method, H, bs, s_q, quant, cache_dtype, draft_token_num, seqlen_incr, mode):
+        slots, max_pages = 64 * 9, 5
+        if quant == "per_token_head":
+            k_cache = (torch.zeros(slots, 1, 512, dtype=torch.uint8), torch.ones(slots, 1, 1), torch.zeros(slots, 1, 64, dtype=torch.bfloat16))
+        else:
+            k_cache = torch.zeros(slots, 1, 576, dtype=cache_dtype)
+        pool = types.SimpleNamespace(get_key_buffer=lambda layer_id: k_cache,
+                                     set_kv_buffer=lambda *a, **k: calls.append({"module": "token_to_kv_pool", "fn": "set_kv_buffer", "args": [describe(x) for x in a[1:]], "kwargs": {}}))
+        fb = types.SimpleNamespace(out_cache_loc=torch.arange(bs * s_q), batch_size=bs, token_to_kv_pool=pool,
+                                   seq_lens=torch.full((bs,), 100, dtype=torch.int64), forward_mode=mode)
+        layer = types.SimpleNamespace(layer_id=0, tp_q_head_num=H, head_dim=576, v_head_dim=512, scaling=192 ** -0.5)
+        meta = types.SimpleNamespace(block_table=torch.zeros(bs + 3, max_pages, dtype=torch.int32),   # graph buffers are larger than bs
+                                     flashmla_metadata=torch.zeros(256, 8, dtype=torch.int32), num_splits=torch.zeros(bs + 1, dtype=torch.int32))
+        self = types.SimpleNamespace(num_q_heads=H, multi_step_seqlen_incr=seqlen_incr, cache_quant_method=quant, cache_dtype=cache_dtype,
+                                     kv_lora_rank=512, qk_rope_head_dim=64, kv_cache_dim=576, forward_metadata=meta,
+                                     draft_token_num=draft_token_num)
+        self.get_flash_mla_module = lambda M: module_fn(M, self.cache_quant_method)
+        q = torch.zeros(bs * s_q, H * 576, dtype=torch.bfloat16)
+        k = torch.zeros(bs * s_q, 1, 576, dtype=torch.bfloat16)
+        n0 = len(calls)
+        out = method(self, q, k, k, layer, fb, True)
+        return {"case": tag, "H": H, "bs": bs, "s_q": s_q, "quant_method": quant, "cache_dtype": str(cache_dtype).replace("torch.", ""),
+                "calls": calls[n0:], "returned": describe(out)}
+
+    DEC, VER = ForwardMode.DECODE, ForwardMode.TARGET_VERIFY
+    trace = [run("decode per-token fp8, H=128", forward_decode, 128, 3, 1, "per_token_head", torch.float8_e4m3fn, 0, 0, DEC),
+             run("decode per-token fp8, H=16 (TP8 shard), MTP draft step 2", forward_decode, 16, 2, 1, "per_token_head", torch.float8_e4m3fn, 4, 2, DEC),
+             run("decode plain fp8 cache, H=128 -> flash_mla_fp8", forward_decode, 128, 2, 1, "none", torch.float8_e4m3fn, 0, 0, DEC),
+             run("decode plain fp8 cache, H=16 -> flash_mla_swap", forward_decode, 16, 2, 1, "none", torch.float8_e4m3fn, 0, 0, DEC),
+             run("decode bf16 cache, H=16 -> flash_mla_swap", forward_decode, 16, 2, 1, "none", torch.bfloat16, 0, 0, DEC),
+             run("verify s_q=4 per-token fp8, H=128", forward_extend, 128, 2, 4, "per_token_head", torch.float8_e4m3fn, 4, 0, VER),
+             run("verify s_q=4 bf16 cache, H=8 -> flash_mla_swap", forward_extend, 8, 2, 4, "none", torch.bfloat16, 4, 0, VER)]
+    with open(os.path.join(OUT, "flashmla_backend_call_trace.json"), "w") as f:
+        json.dump({"source": "python/sglang/srt/layers/attention/flashmla_backend.py:88-256 exec'd by oracle/gen_golden.py:gen_call_trace",
+                   "trace": trace}, f, indent=1)
+    print("call trace:", sum(len(t["calls"]) for t in trace), "calls in", len(trace), "cases")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--only-call-trace" in sys.argv:
+        gen_call_trace()
+        sys.exit(0)
     if "--only-ep" in sys.argv:
         gen_ep_scatter_gather()
         sys.exit(0)
@@ -382,3 +477,4 @@ if __name__ == "__main__":
     if os.environ.get("TRITON_INTERPRET") == "1":
         gen_ep_scatter_gather()
     print("golden written to", OUT)
+    gen_call_trace()

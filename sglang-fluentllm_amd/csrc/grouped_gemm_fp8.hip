@@ -19,6 +19,7 @@
 //
 // Algorithmic bytes / flops per MoE layer: SURVEY.md §8(d) (weights 44.04 MB per expert hit, 88.08 MFLOP per row).
 #include "grouped_gemm_shared.h"
+#include <atomic>
 #include <cstdlib>
 
 using namespace fl_gemm;
@@ -108,24 +109,23 @@ __device__ __forceinline__ void kblock_body(v16f (&acc)[MT], const uint8_t* __re
   }
 }
 
+// One output tile (or one k split of it) of one workgroup.  `bid` is the tile index: blockIdx.x for an ordinary launch, or
+// the loop variable of a persistent launch capped by deep_gemm.set_num_sms (grouped_gemm_fp8_kernel below).
 template <int MT>
-__global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void grouped_gemm_fp8_kernel(const GemmParams p, const uint8_t* __restrict__ gA,
-                                                                   const float* __restrict__ gAs,
-                                                                   const uint8_t* __restrict__ gW,
-                                                                   const float* __restrict__ gWs,
-                                                                   const int32_t* __restrict__ gmeta) {
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const uint8_t* __restrict__ gA, const float* __restrict__ gAs,
+                                          const uint8_t* __restrict__ gW, const float* __restrict__ gWs,
+                                          const int32_t* __restrict__ gmeta, uint8_t* __restrict__ smem, const int bid) {
   constexpr int BM = 32 * MT;
   constexpr int kStages = Smem<MT>::kStages;
   static_assert(Smem<MT>::kPiecesPerWave * (kStages - 2) == (MT == 1 ? 6 : MT == 2 ? 7 : 10 * (FL_MT4_STAGES - 2)), "vmcnt immediates");
-  __shared__ __attribute__((aligned(16))) uint8_t smem[Smem<MT>::kTotal];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
 
   // ---- tile -> (expert, token range, weight tile) ----
-  const int split = p.ksplit > 1 ? blockIdx.x % p.ksplit : 0;   // split-K: the k blocks of a tile over ksplit workgroups
-  const int tile = p.ksplit > 1 ? blockIdx.x / p.ksplit : blockIdx.x;
+  const int split = p.ksplit > 1 ? bid % p.ksplit : 0;   // split-K: the k blocks of a tile over ksplit workgroups
+  const int tile = p.ksplit > 1 ? bid / p.ksplit : bid;
   const int nt = tile % p.n_tiles;
   const int mt = tile / p.n_tiles;
   int e = 0;
@@ -261,6 +261,23 @@ __global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void g
   }
 }
 
+// Ordinary launch: one workgroup per tile (gridDim.x = total_blocks, one trip).  With deep_gemm.set_num_sms(n) in force
+// (tbo_executor.py:129-134: the two-batch-overlap executor leaves SMs to the kernels of the other micro-batch) the grid is
+// capped at n workgroups that walk the tile list with stride gridDim.x: at most n workgroup slots of the chip are taken.
+template <int MT>
+__global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void grouped_gemm_fp8_kernel(
+    const GemmParams p, const uint8_t* __restrict__ gA, const float* __restrict__ gAs, const uint8_t* __restrict__ gW,
+    const float* __restrict__ gWs, const int32_t* __restrict__ gmeta) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[Smem<MT>::kTotal];
+  for (int bid = blockIdx.x; bid < p.total_blocks; bid += gridDim.x) {
+    gemm_tile<MT>(p, gA, gAs, gW, gWs, gmeta, smem, bid);
+    if (gridDim.x < (unsigned)p.total_blocks) {   // persistent launch: every wave is done with the LDS ring before the next tile
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+}
+
 // out[m, n] = bf16(sum_s ws[s, m, n]); 4 consecutive columns per thread (N % 4 == 0)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, long long MN,
                                                             uint16_t* __restrict__ out) {
@@ -274,12 +291,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<uint2*>(out + i) = make_uint2(fl_pack_bf16(a.x, a.y), fl_pack_bf16(a.z, a.w));
 }
 
-int g_num_cus_limit = 0;   // deep_gemm.set_num_sms (tbo/tbo_executor.py:129-134): advisory on this path
+// deep_gemm.set_num_sms / get_num_sms (tbo/tbo_executor.py:129-134 saves, sets and restores it around a stage).  The one
+// piece of process-wide state behind the C-ABI, by the reference API's own shape (a module-level setter); 0 = not set
+// (get reports the device's CU count).  A launch reads it once, on the host.
+std::atomic<int> g_num_cus_limit{0};
 
 }  // namespace
 
-extern "C" int fl_gemm_set_num_cus(int n) { g_num_cus_limit = n; return FL_OK; }
-extern "C" int fl_gemm_get_num_cus(void) { return g_num_cus_limit; }
+extern "C" int fl_gemm_set_num_cus(int n) {
+  FL_CHECK_ARG(n >= 0, "fl_gemm_set_num_cus: n=%d", n);
+  g_num_cus_limit.store(n);
+  return FL_OK;
+}
+extern "C" int fl_gemm_get_num_cus(void) {
+  const int n = g_num_cus_limit.load();
+  if (n > 0) return n;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || fl_device_cu_count(dev, &cus) != FL_OK) return 0;
+  return cus;
+}
 
 extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
   FL_CHECK_ARG(a != nullptr, "fl_grouped_gemm_fp8: null args");
@@ -328,8 +358,10 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
   }
   const bool few_tiles = a->mode == kDense && a->workspace != nullptr &&
                          ((a->M + 32 * mt - 1) / (32 * mt)) * (long long)p.n_tiles < 384;
+  // (under a deep_gemm.set_num_sms cap the 128-row kernel's persistent tile walk is used: the 256 x 256 kernel is one
+  //  workgroup per tile by construction)
   if (!few_tiles && big_on && avg >= big_min && a->K >= 2 * BK && a->mode != kContiguous &&
-      (long long)a->N * a->K < (1ll << 32))
+      (long long)a->N * a->K < (1ll << 32) && g_num_cus_limit.load() == 0)
     return fl_gemm_launch_big(p, a->A, a->As, a->W, a->Ws, a->group_meta, (hipStream_t)stream);
   const int bm = 32 * mt;
   long long m_tiles;
@@ -361,7 +393,11 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
     }
   }
   FL_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fl_grouped_gemm_fp8: grid too large");
-  const dim3 grid((unsigned)blocks), block(256);
+  p.total_blocks = (int)blocks;
+  const int cu_cap = g_num_cus_limit.load();
+  long long launch_blocks = blocks;
+  if (cu_cap > 0 && launch_blocks > cu_cap) launch_blocks = cu_cap;   // persistent walk over the tiles (set_num_sms)
+  const dim3 grid((unsigned)launch_blocks), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (mt == 1)
     grouped_gemm_fp8_kernel<1><<<grid, block, 0, s>>>(p, (const uint8_t*)a->A, a->As, (const uint8_t*)a->W, a->Ws, a->group_meta);

@@ -14,6 +14,7 @@ enum Mode { kOffset = 0, kContiguous = 1, kMasked = 2, kDense = 3 };
 struct GemmParams {
   int mode, E, M, N, K;
   int n_tiles, m_tiles_upper;
+  int total_blocks;                     // tiles (x k splits) of the launch; the grid is smaller under deep_gemm.set_num_sms
   long long as_stride_m, as_stride_k, as_stride_g;   // element strides of As (g: masked mode only)
   long long rows_per_group;             // masked mode: padded rows per group
   uint16_t* out;

@@ -2,10 +2,14 @@
 the FP8 MLA-decode / grouped-GEMM hot path: quantization.quant_1x128, sgl_per_token_group_quant_fp8,
 silu_and_mul, activation.silu_and_mul_fuse_block_quant, comm.trtllm_{allreduce,reducescatter,allgather}_fusion, and
 moe_fused_gate (the router selection feeding the EP dispatch, srt/layers/moe/topk.py:33,715) and
-apply_rope_with_cos_sin_cache_inplace (q_pe / k_pe rotation before K5/K4, srt/layers/rotary_embedding.py:31,203).  Sampling / norm / rope / paged-attention wrappers are out of
-scope (not named by the north star)."""
+apply_rope_with_cos_sin_cache_inplace (q_pe / k_pe rotation before K5/K4, srt/layers/rotary_embedding.py:31,203), plus the
+two attention-wrapper classes FlashMLABackend's base class constructs (flashinfer_mla_backend.py:124-142) as INERT objects
+(attention_wrappers.py) and `comm.vllm_ar` (C4).  Sampling / norm / prefill attention are out of scope (not named by the
+north star)."""
 from fluent_mi355.gemm import sgl_per_token_group_quant_fp8, silu_and_mul  # noqa: F401
 from fluent_mi355.router import moe_fused_gate  # noqa: F401
 from fluent_mi355.rope import apply_rope_with_cos_sin_cache_inplace  # noqa: F401
+
+from .attention_wrappers import BatchMLAPagedAttentionWrapper, BatchPrefillWithRaggedKVCacheWrapper  # noqa: F401
 
 from . import activation, comm, quantization  # noqa: F401

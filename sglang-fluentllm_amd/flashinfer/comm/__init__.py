@@ -4,4 +4,4 @@ from fluent_mi355.comm import (AllGatherFusionPattern, AllReduceFusionPattern, R
                                trtllm_create_ipc_workspace_for_all_reduce_fusion,
                                trtllm_destroy_ipc_workspace_for_all_reduce_fusion, trtllm_reducescatter_fusion)
 
-from . import all_gather  # noqa: F401
+from . import all_gather, vllm_ar  # noqa: F401

@@ -53,12 +53,22 @@ def ceil_div(a: int, b: int) -> int:
 
 
 def get_num_sms() -> int:
+    """deep_gemm.get_num_sms: the cap in force, or the device's CU count when none was set (tbo_executor.py:129-134 saves this
+    value and restores it)."""
     return lib.fl_gemm_get_num_cus()
 
 
 def set_num_sms(n: int) -> None:
-    """deep_gemm.set_num_sms (tbo/tbo_executor.py:129-134): recorded; the gfx950 kernels do not partition CUs yet."""
-    lib.fl_gemm_set_num_cus(int(n))
+    """deep_gemm.set_num_sms (tbo/tbo_executor.py:129-134): later grouped / dense GEMM launches take at most `n` workgroup
+    slots (a persistent walk over the tile list), leaving the rest of the chip to the kernels of the other stream.  A
+    value >= the device's CU count (what get_num_sms reports by default) removes the cap."""
+    n = int(n)
+    check(lib.fl_gemm_set_num_cus(0 if n >= _device_cus() else n), "fl_gemm_set_num_cus")
+
+
+def _device_cus() -> int:
+    from ._lib import cu_count
+    return cu_count(torch.device("cuda", torch.cuda.current_device())) if torch.cuda.is_available() else 1 << 30
 
 
 def get_col_major_tma_aligned_tensor(x: torch.Tensor) -> torch.Tensor:

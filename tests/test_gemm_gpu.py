@@ -381,3 +381,60 @@ def test_big_tile_contiguous_and_dense_vs_oracle():
     deep_gemm.gemm_fp8_fp8_bf16_nt((xq1.to(DEV), xs1.to(DEV)), (W1[0].to(DEV), Ws1[0].to(DEV)), out1, True)
     ref1 = gemm_ref.grouped_gemm_offset(xq1, xs1, W1, Ws1, torch.tensor([0, 777], dtype=torch.int32))
     assert rel_mae(out1.cpu(), ref1) < 1e-3
+
+
+def test_set_num_sms_caps_the_grid_and_runs_beside_mla_on_a_second_stream():
+    """deep_gemm.set_num_sms (tbo_executor.py:129-134: save, set, restore) — under a cap the grouped GEMM walks its tiles
+    with at most `n` workgroups (same results), and it can share the chip with an MLA decode launched on another stream
+    inside ONE hipGraph (LongCat runs attention and the MoE GEMMs of two micro-batches concurrently: longcat_flash.py:417-445)."""
+    import deep_gemm
+    import flash_mla_fp8 as fm
+    from helpers import make_paged_case
+
+    counts = [40, 0, 130, 7, 64, 1, 300, 33]
+    N, K = 512, 512
+    xq, xs, W, Ws, ex = make_group_case(counts, N, K, seed=77)
+    M = xq.shape[0]
+    xs_dev = torch.zeros((K // 128, M + 64), dtype=torch.float32, device=DEV).permute(-1, -2)
+    xs_dev[:M] = xs.to(DEV)
+    args = ((xq.to(DEV), xs_dev[:M]), (W.to(DEV), Ws.to(DEV)))
+    ex_dev = ex.to(DEV)
+    ref_out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset(*args, ref_out, ex_dev)
+    full = deep_gemm.get_num_sms()
+    assert full >= 64                       # default: the device's CU count
+    deep_gemm.set_num_sms(24)
+    try:
+        assert deep_gemm.get_num_sms() == 24
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset(*args, out, ex_dev)
+        assert torch.equal(out, ref_out)    # the same tiles, walked by 24 workgroups
+        # MLA decode on a side stream beside the capped GEMM, captured in one graph
+        c = make_paged_case([700, 129, 64], 128, seed=3)
+        d = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in c.items()}
+        pages = c["total_pages"]
+        qn, qs, qr = fm.quantize_ckv_per_token_head(d["q"].contiguous(), 512)
+        meta, ns = fm.get_mla_metadata(d["cache_seqlens"], 128, 1)
+
+        def mla():
+            return fm.flash_mla_ckv_fp8_per_token(qn, qr, d["k_lora"].view(pages, 64, 1, 512), d["k_rope"].view(pages, 64, 1, 64), qs,
+                                                  d["k_scale"].view(pages, 64, 1, 1), d["block_table"], d["cache_seqlens"], 512, meta, ns,
+                                                  192 ** -0.5, True)
+
+        o_ref, _ = mla()
+        torch.cuda.synchronize()
+        out2 = torch.zeros_like(out)
+        side = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                o_g, _ = mla()
+            deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset(*args, out2, ex_dev)
+            torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out2, ref_out) and torch.equal(o_g, o_ref)
+    finally:
+        deep_gemm.set_num_sms(full)         # what tbo_executor does on exit
+    assert deep_gemm.get_num_sms() == full
