@@ -36,6 +36,85 @@ __global__ __launch_bounds__(256) void ep_route_kernel(const int32_t* __restrict
   }
 }
 
+// Token-once-per-peer routing: a token with several experts on one rank travels there ONCE (the receiving rank replicates
+// the row to its experts locally), so a peer slab needs max_tokens rows, not max_tokens * top_k — 8x fewer xGMI bytes than
+// one row per (token, expert) pair at top-8, and a token can never overflow a slab (it occupies at most one row of it).
+//   tok_slot[t, d]      slab row (d*cap + position) of token t in rank d's slab, -1 if none of its experts lives there;
+//                       positions follow the token order (deterministic)
+//   send_eid[row, j]    local expert ids of the row's token on that rank (j-th of them in k order), -1 padded
+//   pair_pos[t, k]      row*top_k + j of pair (t, k): where its combine weight goes
+__global__ __launch_bounds__(256) void ep_route_dedup_kernel(const int32_t* __restrict__ indices, int T, int top_k,
+                                                             int experts_per_rank, int world, int cap,
+                                                             int32_t* __restrict__ tok_slot, int32_t* __restrict__ send_eid,
+                                                             int32_t* __restrict__ pair_pos) {
+  extern __shared__ unsigned long long s_mask[];   // [T] peers of every token (world <= 64)
+  for (long long i = threadIdx.x; i < (long long)world * cap * top_k; i += 256) send_eid[i] = -1;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    unsigned long long m = 0;
+    for (int k = 0; k < top_k; ++k) {
+      const int e = indices[t * top_k + k];
+      if (e >= 0 && e < experts_per_rank * world) m |= 1ull << (e / experts_per_rank);
+    }
+    s_mask[t] = m;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < world) {   // peer d: positions in token order
+    const int d = threadIdx.x;
+    int pos = 0;
+    for (int t = 0; t < T; ++t) {
+      const bool on = (s_mask[t] >> d) & 1ull;
+      tok_slot[t * world + d] = (on && pos < cap) ? d * cap + pos : -1;
+      pos += on ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  __threadfence_block();
+  for (int t = threadIdx.x; t < T; t += 256) {
+    for (int k = 0; k < top_k; ++k) {
+      const int e = indices[t * top_k + k];
+      int pp = -1;
+      if (e >= 0 && e < experts_per_rank * world) {
+        const int d = e / experts_per_rank;
+        const int row = tok_slot[t * world + d];
+        if (row >= 0) {
+          int j = 0;
+          for (int k2 = 0; k2 < k; ++k2) {
+            const int e2 = indices[t * top_k + k2];
+            j += (e2 >= 0 && e2 < experts_per_rank * world && e2 / experts_per_rank == d) ? 1 : 0;
+          }
+          send_eid[(long long)row * top_k + j] = e - d * experts_per_rank;
+          pp = row * top_k + j;
+        }
+      }
+      pair_pos[t * top_k + k] = pp;
+    }
+  }
+}
+
+// out[pos[i]] = vals[i] (pos < 0: skipped); out was zero-filled by the caller's kernel below
+__global__ __launch_bounds__(256) void ep_place_f32_kernel(const float* __restrict__ vals, const int32_t* __restrict__ pos,
+                                                           long long n, long long out_n, float* __restrict__ out) {
+  const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (long long i = i0; i < out_n; i += (long long)gridDim.x * 256) out[i] = 0.f;
+}
+__global__ __launch_bounds__(256) void ep_place_f32_kernel2(const float* __restrict__ vals, const int32_t* __restrict__ pos,
+                                                            long long n, long long out_n, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const long long p = pos[i];
+    if (p >= 0 && p < out_n) out[p] = vals[i];
+  }
+}
+
+// inv[order[i]] = i for i < n (the position of every slot in the sorted order)
+__global__ __launch_bounds__(256) void ep_invert_kernel(const int32_t* __restrict__ order, long long n, int32_t* __restrict__ inv) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const long long o = order[i];
+    if (o >= 0 && o < n) inv[o] = (int32_t)i;
+  }
+}
+
 __global__ __launch_bounds__(256) void ep_sort_kernel(const int32_t* __restrict__ recv_eid, int S, int E,
                                                       int32_t* __restrict__ order, int32_t* __restrict__ exclusive_sum) {
   extern __shared__ int bins[];   // E + 1 counters, then E + 1 cursors
@@ -74,7 +153,8 @@ __global__ __launch_bounds__(256) void ep_rows_kernel(const uint16_t* __restrict
                                                       uint16_t* __restrict__ dst, int src_div) {
   const long long i = blockIdx.x;
   const long long j = idx[i];
-  const long long s = kScatter ? (long long)((unsigned)i / (unsigned)src_div) : j, d = kScatter ? j : i;   // src_div = top_k: pair i carries token i / top_k
+  // scatter: pair i carries token i / src_div (src_div = top_k); gather: index j names pair j of row j / src_div
+  const long long s = kScatter ? (long long)((unsigned)i / (unsigned)src_div) : (j < 0 ? j : j / src_div), d = kScatter ? j : i;
   if (s < 0 || s >= src_rows || d < 0 || d >= dst_rows) return;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const u32x4* sp = reinterpret_cast<const u32x4*>(src + s * hidden);
@@ -108,9 +188,12 @@ __global__ __launch_bounds__(256) void ep_combine_kernel(const uint16_t* __restr
     __syncthreads();
     if (tid < 64 && k0 + tid < top_k) {
       const long long sl = slot[t * top_k + k0 + tid];
-      const bool ok = sl >= 0 && sl < ret_rows;
+      const float wv = w[t * top_k + k0 + tid];
+      // a zero weight skips the row altogether (0 x an uncomputed row must not turn into NaN: the padding pairs of a slab
+      // row sort behind the last expert group, where the expert output buffer was never written)
+      const bool ok = sl >= 0 && sl < ret_rows && wv != 0.f;
       s_slot[tid] = ok ? sl : -1;
-      s_w[tid] = ok ? w[t * top_k + k0 + tid] : 0.f;
+      s_w[tid] = ok ? wv : 0.f;
     }
     __syncthreads();
     const int kn = top_k - k0 < 64 ? top_k - k0 : 64;
@@ -161,6 +244,45 @@ extern "C" int fl_ep_route(const int32_t* indices, int64_t num_pairs, int expert
   FL_CHECK_ARG(world >= 1 && world <= 64 && cap >= 1 && experts_per_rank >= 1 && num_pairs >= 0, "fl_ep_route: bad sizes");
   ep_route_kernel<<<1, 256, 0, (hipStream_t)stream>>>(indices, (int)num_pairs, experts_per_rank, world, cap, send_slot, send_eid);
   FL_CHECK_LAUNCH("fl_ep_route");
+  return FL_OK;
+}
+
+extern "C" int fl_ep_route_dedup(const int32_t* indices, int64_t num_tokens, int top_k, int experts_per_rank, int world, int cap,
+                                 int32_t* tok_slot, int32_t* send_eid, int32_t* pair_pos, fl_stream_t stream) {
+  FL_CHECK_ARG(send_eid && (num_tokens == 0 || (indices && tok_slot && pair_pos)), "fl_ep_route_dedup: null pointer");
+  FL_CHECK_ARG(world >= 1 && world <= 64 && cap >= 1 && experts_per_rank >= 1 && top_k >= 1 && num_tokens >= 0 &&
+                   num_tokens <= 8192, "fl_ep_route_dedup: bad sizes (tokens per rank <= 8192, world <= 64)");
+  ep_route_dedup_kernel<<<1, 256, (size_t)(num_tokens > 0 ? num_tokens : 1) * 8, (hipStream_t)stream>>>(
+      indices, (int)num_tokens, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_pos);
+  FL_CHECK_LAUNCH("fl_ep_route_dedup");
+  return FL_OK;
+}
+
+extern "C" int fl_ep_place_f32(const float* vals, const int32_t* pos, int64_t n, float* out, int64_t out_n, fl_stream_t stream) {
+  FL_CHECK_ARG(out_n >= 0 && n >= 0 && (out || out_n == 0) && (n == 0 || (vals && pos)), "fl_ep_place_f32: bad args");
+  if (out_n == 0) return FL_OK;
+  const long long zb = (out_n + 255) / 256;
+  ep_place_f32_kernel<<<dim3((unsigned)(zb < 1024 ? zb : 1024)), 256, 0, (hipStream_t)stream>>>(vals, pos, n, out_n, out);
+  if (n > 0) ep_place_f32_kernel2<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(vals, pos, n, out_n, out);
+  FL_CHECK_LAUNCH("fl_ep_place_f32");
+  return FL_OK;
+}
+
+extern "C" int fl_ep_invert(const int32_t* order, int64_t n, int32_t* inv, fl_stream_t stream) {
+  if (n == 0) return FL_OK;
+  FL_CHECK_ARG(order && inv && n > 0, "fl_ep_invert: bad args");
+  ep_invert_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(order, n, inv);
+  FL_CHECK_LAUNCH("fl_ep_invert");
+  return FL_OK;
+}
+
+extern "C" int fl_ep_gather_rows_div(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int div, int hidden,
+                                     void* dst, int64_t dst_rows, fl_stream_t stream) {
+  if (n == 0) return FL_OK;
+  FL_CHECK_ARG(src && idx && dst && hidden % 8 == 0 && div >= 1, "fl_ep_gather_rows_div: bad args");
+  ep_rows_kernel<false><<<dim3((unsigned)n), 256, 0, (hipStream_t)stream>>>(
+      (const uint16_t*)src, idx, n, hidden, src_rows, dst_rows, (uint16_t*)dst, div);
+  FL_CHECK_LAUNCH("fl_ep_gather_rows_div");
   return FL_OK;
 }
 

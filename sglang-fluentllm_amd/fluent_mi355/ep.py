@@ -3,10 +3,18 @@ python/sglang/srt/layers/moe/dispatcher/fast_ep.py:16-22,45-51,73-78).
 
 MI355X mapping: xGMI is a point-to-point mesh, so the natural collective is ONE equal-split all-to-all per direction
 over RCCL (`torch.distributed.all_to_all_single`, backend "nccl" = RCCL) on fixed-capacity peer slabs — no counts
-exchange, no host sync, static shapes (hipGraph-friendly).  The integer/row work around the exchange runs in HIP
-kernels (csrc/ep_a2a.hip).  `row_ops` exists so that the multi-process HOST logic can be exercised on CPU tensors with
-the gloo backend in tests (tests/ inject a torch-indexing implementation); the product default is the HIP one and
-there is no automatic fallback."""
+exchange, no host sync, static shapes (hipGraph-friendly).
+
+Slab sizing: a token travels to a rank ONCE, however many of its top-k experts live there (the receiving rank replicates
+the row to its experts locally; on the way back it returns ONE row per token, the weighted sum over its local experts).
+A peer slab therefore holds `max_tokens_per_rank` rows — the true worst case of that scheme, reached only if every token
+of a rank routes to the same peer — instead of `max_tokens_per_rank * top_k` rows for one row per (token, expert) pair:
+8x fewer xGMI bytes at top-8, and a slab cannot overflow (a token occupies at most one row of it).  Per direction:
+  dispatch: rows [world*cap, hidden] + local expert ids [world*cap, top_k] (two all_to_all_single, the second 32 B/row)
+  combine : weights [world*cap, top_k] f32 (tiny) + rows [world*cap, hidden]
+The integer / row work around the exchanges runs in HIP kernels (csrc/ep_a2a.hip).  `row_ops` exists so that the
+multi-process HOST logic can be exercised on CPU tensors with the gloo backend in tests (tests/ inject a torch-indexing
+implementation); the product default is the HIP one and there is no automatic fallback."""
 from __future__ import annotations
 
 import torch
@@ -24,13 +32,17 @@ class HipRowOps:
         self._ct, self._check, self._lib, self._stream = ctypes, check, lib, stream_ptr
         vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
         lib.fl_ep_route.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp]
+        lib.fl_ep_route_dedup.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp]
         lib.fl_ep_sort.argtypes = [vp, i64, i32, vp, vp, vp]
         lib.fl_ep_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
+        lib.fl_ep_gather_rows_div.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp]
         lib.fl_ep_scatter_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
         lib.fl_ep_send_rows.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp]
         lib.fl_ep_combine.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp]
-        for n in ("fl_ep_route", "fl_ep_sort", "fl_ep_gather_rows", "fl_ep_scatter_rows", "fl_ep_send_rows",
-                  "fl_ep_combine"):
+        lib.fl_ep_place_f32.argtypes = [vp, vp, i64, vp, i64, vp]
+        lib.fl_ep_invert.argtypes = [vp, i64, vp, vp]
+        for n in ("fl_ep_route", "fl_ep_route_dedup", "fl_ep_sort", "fl_ep_gather_rows", "fl_ep_gather_rows_div",
+                  "fl_ep_scatter_rows", "fl_ep_send_rows", "fl_ep_combine", "fl_ep_place_f32", "fl_ep_invert"):
             getattr(lib, n).restype = i32
 
     @staticmethod
@@ -41,31 +53,38 @@ class HipRowOps:
             raise RuntimeError("expected a CUDA/HIP tensor")
         return stream_ptr(t.device)
 
-    def route(self, indices, experts_per_rank, world, cap, send_slot, send_eid):
-        self._check(self._lib.fl_ep_route(indices.data_ptr(), indices.numel(), experts_per_rank, world, cap,
-                                          send_slot.data_ptr(), send_eid.data_ptr(), self._stream(indices.device)), "fl_ep_route")
+    def route_dedup(self, indices, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_pos):
+        self._check(self._lib.fl_ep_route_dedup(indices.data_ptr(), indices.numel() // top_k, top_k, experts_per_rank, world, cap,
+                                                tok_slot.data_ptr(), send_eid.data_ptr(), pair_pos.data_ptr(),
+                                                self._stream(send_eid.device)), "fl_ep_route_dedup")
 
     def sort(self, recv_eid, num_local_experts, order, exclusive_sum):
         self._check(self._lib.fl_ep_sort(recv_eid.data_ptr(), recv_eid.numel(), num_local_experts, order.data_ptr(),
                                          exclusive_sum.data_ptr(), self._stream(recv_eid.device)), "fl_ep_sort")
 
-    def gather(self, src, idx, n, dst):
-        self._check(self._lib.fl_ep_gather_rows(src.data_ptr(), src.shape[0], idx.data_ptr(), n, src.shape[1], dst.data_ptr(),
-                                                dst.shape[0], self._stream(src.device)), "fl_ep_gather_rows")
+    def gather_div(self, src, idx, n, div, dst):
+        """dst[i] = src[idx[i] // div] for i < n"""
+        self._check(self._lib.fl_ep_gather_rows_div(src.data_ptr(), src.shape[0], idx.data_ptr(), n, div, src.shape[1],
+                                                    dst.data_ptr(), dst.shape[0], self._stream(src.device)), "fl_ep_gather_rows_div")
 
-    def scatter(self, src, idx, n, dst):
-        self._check(self._lib.fl_ep_scatter_rows(src.data_ptr(), src.shape[0], idx.data_ptr(), n, src.shape[1], dst.data_ptr(),
-                                                 dst.shape[0], self._stream(src.device)), "fl_ep_scatter_rows")
+    def send(self, x, send_slot, per_token, send_buf):
+        """send_buf[send_slot[p]] = x[p // per_token] for every entry p with a slot"""
+        self._check(self._lib.fl_ep_send_rows(x.data_ptr(), x.shape[0], send_slot.data_ptr(), send_slot.numel(), per_token, x.shape[1],
+                                              send_buf.data_ptr(), send_buf.shape[0], self._stream(send_buf.device)), "fl_ep_send_rows")
 
-    def send(self, x, send_slot, top_k, send_buf):
-        """send_buf[send_slot[p]] = x[p // top_k] for every (token, expert) pair p with a slot"""
-        self._check(self._lib.fl_ep_send_rows(x.data_ptr(), x.shape[0], send_slot.data_ptr(), send_slot.numel(), top_k, x.shape[1],
-                                              send_buf.data_ptr(), send_buf.shape[0], self._stream(x.device)), "fl_ep_send_rows")
-
-    def combine(self, ret, send_slot, weights, out, top_k):
-        self._check(self._lib.fl_ep_combine(ret.data_ptr(), ret.shape[0], send_slot.data_ptr(), weights.data_ptr(),
-                                            out.shape[0], top_k, out.shape[1], out.data_ptr(), self._stream(ret.device)),
+    def combine(self, rows, slot, weights, out, per_token):
+        """out[t] = sum_j weights[t, j] * rows[slot[t, j]] (slots < 0 or >= len(rows): skipped), fp32 accumulate"""
+        self._check(self._lib.fl_ep_combine(rows.data_ptr(), rows.shape[0], slot.data_ptr(), weights.data_ptr(),
+                                            out.shape[0], per_token, out.shape[1], out.data_ptr(), self._stream(out.device)),
                     "fl_ep_combine")
+
+    def place_f32(self, vals, pos, out):
+        """out = 0; out[pos[i]] = vals[i]"""
+        self._check(self._lib.fl_ep_place_f32(vals.data_ptr(), pos.data_ptr(), vals.numel(), out.data_ptr(), out.numel(),
+                                              self._stream(out.device)), "fl_ep_place_f32")
+
+    def invert(self, order, inv):
+        self._check(self._lib.fl_ep_invert(order.data_ptr(), order.numel(), inv.data_ptr(), self._stream(order.device)), "fl_ep_invert")
 
 
 class AllToAll:
@@ -80,11 +99,18 @@ class AllToAll:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         if self.num_experts % self.world:
             raise RuntimeError("num_experts must divide evenly over the EP group")
+        if self.world > 64:
+            raise RuntimeError("AllToAll: at most 64 ranks (peer sets are 64-bit masks)")
         self.experts_per_rank = self.num_experts // self.world
         self.max_tokens_per_rank = max(1, int(max_tokens) // self.world)
-        self.cap = self.max_tokens_per_rank * self.top_k          # rows of one peer slab (worst case: all pairs to one peer)
+        self.cap = self.max_tokens_per_rank                       # rows of one peer slab: one row per (token, peer)
         self.row_ops = row_ops if row_ops is not None else HipRowOps()
         self._state = None
+        self._ones = None
+
+    def slab_bytes(self, dtype_size=2):
+        """bytes one rank puts on the wire per direction (rows only)"""
+        return self.world * self.cap * self.hidden * dtype_size
 
     def _a2a(self, inp):
         if self.world == 1:
@@ -106,36 +132,49 @@ class AllToAll:
             raise RuntimeError("AllToAll: hidden must be a multiple of 8")
         if t > self.max_tokens_per_rank:
             raise RuntimeError(f"{t} local tokens exceed the capacity {self.max_tokens_per_rank} this AllToAll was built for")
-        dev, S = dp_x.device, self.world * self.cap
+        dev, W, K = dp_x.device, self.world, self.top_k
+        S = W * self.cap
         idx = indices.reshape(-1).contiguous()
-        send_slot = torch.empty(idx.numel(), dtype=torch.int32, device=dev)
-        send_eid = torch.empty(S, dtype=torch.int32, device=dev)
-        self.row_ops.route(idx, self.experts_per_rank, self.world, self.cap, send_slot, send_eid)
-        send_buf = torch.empty(S, self.hidden, dtype=dp_x.dtype, device=dev)   # empty slots: never read (send_eid = -1)
-        self.row_ops.send(dp_x.contiguous(), send_slot, self.top_k, send_buf)
+        tok_slot = torch.empty(t * W, dtype=torch.int32, device=dev)
+        pair_pos = torch.empty(t * K, dtype=torch.int32, device=dev)
+        send_eid = torch.empty(S * K, dtype=torch.int32, device=dev)
+        self.row_ops.route_dedup(idx, K, self.experts_per_rank, W, self.cap, tok_slot, send_eid, pair_pos)
+        send_buf = torch.empty(S, self.hidden, dtype=dp_x.dtype, device=dev)   # empty rows: never read (all their eids are -1)
+        self.row_ops.send(dp_x.contiguous(), tok_slot, W, send_buf)
         recv_buf = self._a2a(send_buf)
         recv_eid = self._a2a(send_eid)
-        order = torch.empty(S, dtype=torch.int32, device=dev)
+        # received (row, j) pairs grouped by local expert; a row with several local experts is replicated HERE
+        order = torch.empty(S * K, dtype=torch.int32, device=dev)
         self.row_ops.sort(recv_eid, self.experts_per_rank, order, out_exclusive_sum)
-        n_out = min(out_expert_x.shape[0], S)
-        self.row_ops.gather(recv_buf, order, n_out, out_expert_x)
-        self._state = (send_slot, order, n_out, S)
+        n_out = min(out_expert_x.shape[0], S * K)
+        self.row_ops.gather_div(recv_buf, order, n_out, K, out_expert_x)
+        self._state = (tok_slot, pair_pos, order, n_out, S)
         return out_expert_x, out_exclusive_sum
 
     def combine(self, out_tokens, weights, expert_y, num_global_tokens):
         if self._state is None:
             raise RuntimeError("combine() without a preceding dispatch()")
-        send_slot, order, n_out, S = self._state
-        dev = expert_y.device
+        tok_slot, pair_pos, order, n_out, S = self._state
+        dev, W, K = expert_y.device, self.world, self.top_k
         if expert_y.element_size() != 2 or expert_y.shape[1] != self.hidden:
             raise RuntimeError(f"AllToAll.combine: expert_y must be a 2-byte [rows, {self.hidden}] tensor")
-        if weights.numel() != out_tokens.shape[0] * self.top_k:
+        if weights.numel() != out_tokens.shape[0] * K:
             raise RuntimeError("AllToAll.combine: weights must hold tokens x top_k values")
-        # rows nobody computed (out_expert_x shorter than the slab) must come back as zeros, not as stale memory
-        back = (torch.empty if n_out >= S else torch.zeros)(S, self.hidden, dtype=expert_y.dtype, device=dev)
-        self.row_ops.scatter(expert_y, order, n_out, back)
+        # the pairs' weights travel to the expert ranks in the layout of the expert ids (0 where a row has no j-th expert)
+        send_w = torch.empty(S * K, dtype=torch.float32, device=dev)
+        self.row_ops.place_f32(weights.to(torch.float32).reshape(-1).contiguous(), pair_pos, send_w)
+        recv_w = self._a2a(send_w)
+        # expert rank: ONE row per received token = weighted sum over its local experts (rows nobody computed — pairs beyond
+        # expert_y — and empty slab rows contribute nothing: their weight is 0 / their position is out of range)
+        inv = torch.full((S * K,), -1, dtype=torch.int32, device=dev)
+        self.row_ops.invert(order, inv)
+        back = torch.empty(S, self.hidden, dtype=expert_y.dtype, device=dev)
+        self.row_ops.combine(expert_y[:n_out] if n_out < expert_y.shape[0] else expert_y, inv, recv_w, back, K)
         ret = self._a2a(back)
-        self.row_ops.combine(ret, send_slot, weights.to(torch.float32).contiguous(), out_tokens, self.top_k)
+        # home rank: sum of the (at most `world`) rows that came back for every token
+        if self._ones is None or self._ones.numel() < tok_slot.numel() or self._ones.device != dev:
+            self._ones = torch.ones(max(tok_slot.numel(), 1), dtype=torch.float32, device=dev)
+        self.row_ops.combine(ret, tok_slot, self._ones, out_tokens, W)
         return out_tokens
 
 

@@ -5,18 +5,32 @@ import torch
 
 
 class TorchRowOps:
-    def route(self, indices, experts_per_rank, world, cap, send_slot, send_eid):
+    def route_dedup(self, indices, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_pos):
         send_eid.fill_(-1)
-        cursor = [0] * world
-        for p, e in enumerate(indices.tolist()):
-            slot = -1
-            if 0 <= e < experts_per_rank * world:
-                d = e // experts_per_rank
-                if cursor[d] < cap:
-                    slot = d * cap + cursor[d]
-                    send_eid[slot] = e - d * experts_per_rank
-                    cursor[d] += 1
-            send_slot[p] = slot
+        ids = indices.view(-1, top_k).tolist()
+        T = len(ids)
+        ts = [[-1] * world for _ in range(T)]
+        pos = [0] * world
+        for t in range(T):
+            peers = sorted({e // experts_per_rank for e in ids[t] if 0 <= e < experts_per_rank * world})
+            for d in peers:
+                if pos[d] < cap:
+                    ts[t][d] = d * cap + pos[d]
+                pos[d] += 1
+        for t in range(T):
+            seen = [0] * world
+            for k, e in enumerate(ids[t]):
+                pp = -1
+                if 0 <= e < experts_per_rank * world:
+                    d = e // experts_per_rank
+                    row = ts[t][d]
+                    if row >= 0:
+                        send_eid[row * top_k + seen[d]] = e - d * experts_per_rank
+                        pp = row * top_k + seen[d]
+                    seen[d] += 1
+                pair_pos[t * top_k + k] = pp
+        if T:
+            tok_slot.copy_(torch.tensor(ts, dtype=torch.int32).view(-1))
 
     def sort(self, recv_eid, E, order, exclusive_sum):
         key = torch.where((recv_eid >= 0) & (recv_eid < E), recv_eid, torch.full_like(recv_eid, E))
@@ -25,23 +39,27 @@ class TorchRowOps:
         exclusive_sum[0] = 0
         exclusive_sum[1:] = torch.cumsum(counts, 0).to(torch.int32)
 
-    def gather(self, src, idx, n, dst):
-        i = idx[:n].long()
-        ok = (i >= 0) & (i < src.shape[0])
+    def gather_div(self, src, idx, n, div, dst):
+        i = idx[:n].long() // div
+        ok = (idx[:n] >= 0) & (i < src.shape[0])
         dst[:n][ok] = src[i[ok]]
 
-    def scatter(self, src, idx, n, dst):
-        i = idx[:n].long()
-        ok = (i >= 0) & (i < dst.shape[0])
-        dst[i[ok]] = src[:n][ok]
-
-    def send(self, x, send_slot, top_k, send_buf):
+    def send(self, x, send_slot, per_token, send_buf):
         s = send_slot.long()
         ok = (s >= 0) & (s < send_buf.shape[0])
-        send_buf[s[ok]] = x[torch.arange(s.numel())[ok] // top_k]
+        send_buf[s[ok]] = x[torch.arange(s.numel())[ok] // per_token]
 
-    def combine(self, ret, send_slot, weights, out, top_k):
-        s = send_slot.view(-1, top_k).long()
-        ok = (s >= 0).unsqueeze(-1)
-        rows = ret[s.clamp_min(0)].float() * ok
-        out.copy_((rows * weights.view(-1, top_k, 1)).sum(1).to(out.dtype))
+    def combine(self, rows, slot, weights, out, per_token):
+        s = slot.view(-1, per_token).long()
+        w = weights.reshape(-1)[:s.numel()].view(-1, per_token)
+        ok = ((s >= 0) & (s < rows.shape[0]) & (w != 0)).unsqueeze(-1)
+        r = torch.where(ok, rows[s.clamp(0, max(rows.shape[0] - 1, 0))].float(), torch.zeros(())) if rows.shape[0] else torch.zeros(s.shape + (out.shape[1],))
+        out.copy_((r * w.unsqueeze(-1)).sum(1).to(out.dtype))
+
+    def place_f32(self, vals, pos, out):
+        out.zero_()
+        ok = pos >= 0
+        out[pos[ok].long()] = vals[ok]
+
+    def invert(self, order, inv):
+        inv[order.long()] = torch.arange(order.numel(), dtype=torch.int32)

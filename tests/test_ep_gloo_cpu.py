@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, t_per_rank):
+def _worker(rank, world, port, t_per_rank, one_peer=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "sglang-fluentllm_amd"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -34,8 +34,11 @@ def _worker(rank, world, port, t_per_rank):
         T_g = sum(t_per_rank)
         x = torch.randn(t, HID, generator=g).to(torch.bfloat16)
         idx = torch.stack([torch.randperm(E, generator=g)[:K] for _ in range(t)]).to(torch.int32) if t else torch.zeros(0, K, dtype=torch.int32)
+        if one_peer and t:                                     # worst case of the slab sizing: EVERY token of every rank goes to rank 1
+            idx = torch.stack([torch.randperm(E // world, generator=g)[:K] + E // world for _ in range(t)]).to(torch.int32)
         w = torch.rand(t, K, generator=g)
         a2a = AllToAll(K, E, HID, max(t_per_rank) * world, None, row_ops=TorchRowOps())
+        assert a2a.cap == max(t_per_rank) and a2a.slab_bytes() == world * max(t_per_rank) * HID * 2   # one row per (token, peer)
         ex = torch.empty(E // world + 1, dtype=torch.int32)
         expert_x = torch.zeros(T_g * K, HID, dtype=torch.bfloat16)
         a2a.dispatch(out_exclusive_sum=ex, out_expert_x=expert_x, dp_x=x, indices=idx, num_global_tokens=T_g)
@@ -46,7 +49,7 @@ def _worker(rank, world, port, t_per_rank):
         mine = [sum(1 for e in flat if e == rank * (E // world) + le) for le in range(E // world)]
         assert ex.tolist() == [0] + torch.cumsum(torch.tensor(mine), 0).tolist(), (ex.tolist(), mine)
         # "expert compute": local expert le scales its rows by (global expert id + 1)
-        y = torch.zeros_like(expert_x)
+        y = torch.full_like(expert_x, float("nan"))            # rows no expert computed must never reach a token
         for le in range(E // world):
             lo, hi = int(ex[le]), int(ex[le + 1])
             y[lo:hi] = (expert_x[lo:hi].float() * (rank * (E // world) + le + 1)).to(torch.bfloat16)
@@ -66,3 +69,9 @@ def _worker(rank, world, port, t_per_rank):
 def test_ep_all_to_all_world2_gloo(t_per_rank):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, t_per_rank), nprocs=2, join=True)
+
+
+def test_ep_all_to_all_world2_gloo_every_token_to_one_peer():
+    """The peer slab holds max_tokens_per_rank rows (a token travels to a rank once): full slabs, nothing dropped."""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, [6, 6], True), nprocs=2, join=True)

@@ -326,7 +326,7 @@ def test_ep_all_to_all_single_rank_hip_row_ops():
     counts = torch.bincount(idx.reshape(-1).long(), minlength=E)
     assert ex.cpu().tolist() == [0] + torch.cumsum(counts, 0).tolist()
     exc = ex.cpu()
-    y = torch.zeros_like(expert_x)
+    y = torch.full_like(expert_x, float("nan"))
     for e in range(E):
         y[int(exc[e]):int(exc[e + 1])] = (expert_x[int(exc[e]):int(exc[e + 1])].float() * (e + 1)).to(torch.bfloat16)
         # every row grouped under expert e is a token that selected e
@@ -334,6 +334,52 @@ def test_ep_all_to_all_single_rank_hip_row_ops():
     a2a.combine(out_tokens=out, weights=w.to(DEV), expert_y=y, num_global_tokens=t)
     ref = sum(w[:, k:k + 1] * (x.float() * (idx[:, k:k + 1].float() + 1)).to(torch.bfloat16).float() for k in range(K)).to(torch.bfloat16)
     assert torch.allclose(out.cpu().float(), ref.float(), atol=2e-2, rtol=2e-2)
+
+
+def test_ep_dedup_row_kernels_match_the_torch_row_ops_world4_routing():
+    """The token-once-per-peer routing kernels (route_dedup / place_f32 / invert / gather_div) against the torch-indexing
+    implementation the gloo tests inject, with the routing of a 4-rank job (no exchange needed to compare the kernels)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ep_torch_ops import TorchRowOps
+    from fluent_mi355.ep import HipRowOps
+
+    hip, ref = HipRowOps(), TorchRowOps()
+    W, EPR, K, T, HID = 4, 8, 8, 53, 128
+    cap = 40                                                   # < T on purpose: rows past the slab end are dropped the same way
+    g = torch.Generator().manual_seed(77)
+    idx = torch.stack([torch.randperm(W * EPR, generator=g)[:K] for _ in range(T)]).to(torch.int32)
+    idx[3, 2] = -1                                              # an invalid id is ignored by both
+    outs = []
+    for ops, dev in ((ref, "cpu"), (hip, DEV)):
+        ts = torch.empty(T * W, dtype=torch.int32, device=dev)
+        pp = torch.empty(T * K, dtype=torch.int32, device=dev)
+        se = torch.empty(W * cap * K, dtype=torch.int32, device=dev)
+        ops.route_dedup(idx.to(dev).reshape(-1), K, EPR, W, cap, ts, se, pp)
+        vals = torch.rand(T * K, generator=torch.Generator().manual_seed(5)).to(dev)
+        placed = torch.empty(W * cap * K, dtype=torch.float32, device=dev)
+        ops.place_f32(vals, pp, placed)
+        order = torch.empty(W * cap * K, dtype=torch.int32, device=dev)
+        ex = torch.empty(EPR + 1, dtype=torch.int32, device=dev)
+        ops.sort(se, EPR, order, ex)
+        inv = torch.full((W * cap * K,), -1, dtype=torch.int32, device=dev)
+        ops.invert(order, inv)
+        src = torch.randn(W * cap, HID, generator=torch.Generator().manual_seed(6)).to(torch.bfloat16).to(dev)
+        n = int(ex[-1])
+        dst = torch.zeros(n, HID, dtype=torch.bfloat16, device=dev)
+        ops.gather_div(src, order, n, K, dst)
+        outs.append([t.cpu() for t in (ts, pp, se, placed, ex)])
+        # the order INSIDE an expert group is free (the device sort hands positions out with atomics): check it by meaning
+        o, sec, exc = order.cpu().long(), se.cpu(), ex.cpu()
+        assert sorted(o.tolist()) == list(range(W * cap * K))
+        for e in range(EPR):
+            assert bool((sec[o[int(exc[e]):int(exc[e + 1])]] == e).all())
+        assert bool((sec[o[n:]] < 0).all())
+        assert torch.equal(inv.cpu().long()[o], torch.arange(W * cap * K))
+        assert torch.equal(dst.cpu(), src.cpu()[o[:n] // K])
+    for a, b in zip(*outs):                                     # slab positions are handed out in token order by both
+        assert torch.equal(a, b)
 
 
 def test_masked_big_tile_vs_oracle():
