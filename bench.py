@@ -203,6 +203,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-gemm", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--mode", choices=["mla", "cfg4"], default="mla",
+                    help="mla (default): the headline DP-attention MLA decode bench; cfg4: BASELINE config 4, attention-TP + EP MoE "
+                         "decoder layers with the path's collectives (all-gather, reduce-scatter, EP all-to-all) over RCCL")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,6 +222,9 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if a.mode == "cfg4":
+        return main_cfg4(a, dev, world, rank, dist)
 
     import flash_mla_fp8 as fm
 
@@ -267,7 +273,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
-    tokens_per_s = world * BS / (ms_per_step * 1e-3) * (LAYERS / layers)
+    tokens_per_s = world * BS / (ms_per_step * 1e-3) * (layers / LAYERS)   # (a step of fewer layers is scaled to the 61-layer step)
 
     # ---- roofline of the dominant kernel: K1 alone, HIP events on the launch stream (torch's current stream) ----
     roof = None
@@ -349,6 +355,68 @@ def main():
                        "bs_per_gpu": BS, "seq_len": SEQ, "heads": H, "layers_per_step": layers,
                        "parallelism": f"dp{world} (DP-attention, no data-path collective)", "hipgraph": graph is not None},
             "roofline": roof, "gemm": gemm, "cpu_baseline": cpu}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main_cfg4(a, dev, world, rank, dist):
+    """BASELINE config 4 (TP8/EP8 decoder layers, bs=256, seq=8192): the multi-rank form of the path, every collective a
+    real RCCL call inside the captured step.  The global batch is fixed (strong scaling); `value` = tokens/s of the job
+    scaled to 61 layers.  Static shapes throughout, so the step is one hipGraph (eager if the capture is refused)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import cfg4_layer
+
+    layers = a.layers if a.layers != LAYERS else (2 if world == 1 else 4)
+    step, info = cfg4_layer.build(dev, world, rank, None, layers)
+    step()
+    torch.cuda.synchronize()
+    graph, why = None, None
+    if not a.no_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+        except Exception as ex:   # a refused capture is reported, not hidden: the step then runs eagerly
+            graph, why = None, f"{type(ex).__name__}: {ex}"[:200]
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+    for _ in range(a.warmup):
+        run()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    if rank == 0:
+        print(json.dumps({
+            "metric": "decode tokens/s, DeepSeek-V3 decoder layers at BASELINE config 4 (attention-TP + EP MoE, bs=256 seq=8k), scaled to 61 layers",
+            "value": round(info["bs"] / (ms_per_step * 1e-3) * (layers / LAYERS), 1), "unit": "tokens/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "ms_per_layer": round(ms_per_step / layers, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "fp8_e4m3 x fp8 -> f32 acc (attention, GEMMs); bf16 activations on the wire", "data": "synthetic",
+            "config": {"workload": f"DeepSeek-V3 decoder layer x{layers}: TP{world} MLA decode (H={info['heads_per_rank']}/rank, bs=256 "
+                                   f"seq=8192) + EP{world} MoE ({info['experts_per_rank']} experts/rank, top-8), all-gather + "
+                                   "reduce-scatter + EP dispatch/combine over RCCL inside the step",
+                       "layers_per_step": layers, "parallelism": f"tp{world}/ep{world}", "hipgraph": graph is not None,
+                       "hipgraph_refused": why, **info},
+            "roofline": None, "cpu_baseline": None}))
     if dist is not None:
         dist.destroy_process_group()
 

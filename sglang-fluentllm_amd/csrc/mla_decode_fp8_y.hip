@@ -118,6 +118,9 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
   asm volatile("" : "+v"(kb0));
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
+#ifdef FL_Y_HALFK   // experiment: half of the K operand reads (results are garbage)
+    if (s >= 4) { ka[s][0] = ka[s - 4][0]; ka[s][1] = ka[s - 4][1]; continue; }
+#endif
     ka[s][0] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6)) + (s >> 2) * 256);
     ka[s][1] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6) ^ 16) + (s >> 2) * 256);
   }
@@ -292,6 +295,9 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, con
 #endif
   v8i va[8];
   auto load_vt = [&](int jb) {
+#ifdef FL_Y_HALFV   // experiment: half of the V^T operand reads (results are garbage)
+    if (jb & 1) { va[jb] = va[jb - 1]; return; }
+#endif
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint8_t* ap = vp + (lc.vb0 ^ (((jb & 3) << 4) | ((jb >> 2) << 7))) + (u & 1) * (16 * kDN) + (u >> 1) * (32 * kDN);

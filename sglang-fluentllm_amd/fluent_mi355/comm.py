@@ -171,12 +171,30 @@ def _sum_pieces(pieces, out):
         out.copy_(tmp)
 
 
-def _gather_rows_uneven(rows, counts, rank, total, group):
-    """every rank contributes `rows` [counts[rank], H] -> [total, H] on every rank (ONE uneven all_to_all_single)."""
-    out = torch.empty((total,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+_compact_idx = {}
+
+
+def _gather_rows_uneven(rows, counts, rank, total, group, out=None):
+    """every rank contributes `rows` [counts[rank], H] -> [total, H] on every rank: ONE all-gather (RCCL sends every row
+    once per peer; nothing is replicated locally).  Counts from `get_num_tokens_per_rank` differ by at most one row: the
+    uneven case gathers slices padded to the largest count and compacts them with one indexed copy."""
     W = len(counts)
-    dist.all_to_all_single(out, rows.contiguous().repeat(W, 1), output_split_sizes=counts,
-                           input_split_sizes=[counts[rank]] * W, group=group)
+    if out is None:
+        out = torch.empty((total,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    cmax = max(counts)
+    if all(c == cmax for c in counts) and out.is_contiguous():
+        dist.all_gather_into_tensor(out, rows.contiguous(), group=group)
+        return out
+    padded = rows.new_zeros((cmax,) + tuple(rows.shape[1:]))
+    padded[:counts[rank]].copy_(rows)
+    buf = torch.empty((W * cmax,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    key = (tuple(counts), str(rows.device))
+    idx = _compact_idx.get(key)
+    if idx is None:
+        idx = torch.tensor([r * cmax + i for r in range(W) for i in range(counts[r])], dtype=torch.int64, device=rows.device)
+        _compact_idx[key] = idx
+    torch.index_select(buf, 0, idx, out=out)
     return out
 
 
@@ -271,8 +289,7 @@ def trtllm_allgather_fusion(allgather_in, world_size, world_rank, hidden_dim, wo
     else:
         counts = get_num_tokens_per_rank(W, num_token_all_group)
         assert counts[world_rank] == t_cur, "token split does not follow get_num_tokens_per_rank"
-        send = allgather_in.contiguous().repeat(W, 1)            # the same rows to every peer
-        dist.all_to_all_single(allgather_out, send, output_split_sizes=counts, input_split_sizes=[t_cur] * W, group=ws.group)
+        _gather_rows_uneven(allgather_in, counts, world_rank, num_token_all_group, ws.group, out=allgather_out[:num_token_all_group])
     if pattern_code is not None and int(pattern_code) == int(AllGatherFusionPattern.kAllGather):
         return
     _ops().dual_rmsnorm(allgather_out, q_lora_rank, kv_lora_rank, x_rms_gamma, y_rms_gamma, x_rms_eps, y_rms_eps, x_norm_out,
@@ -387,5 +404,4 @@ class TPDPConvertor:
         if W == 1:
             ctx.output().copy_(ctx.input())
             return
-        dist.all_to_all_single(ctx.output(), ctx.input().repeat(W, 1), output_split_sizes=ctx.counts,
-                               input_split_sizes=[mine] * W, group=self.group)
+        _gather_rows_uneven(ctx.input(), ctx.counts, self.rank, sum(ctx.counts), self.group, out=ctx.output())

@@ -75,3 +75,52 @@ def test_ep_all_to_all_world2_gloo_every_token_to_one_peer():
     """The peer slab holds max_tokens_per_rank rows (a token travels to a rank once): full slabs, nothing dropped."""
     port = _free_port()
     mp.spawn(_worker, args=(2, port, [6, 6], True), nprocs=2, join=True)
+
+
+def _replay_worker(rank, world, port):
+    """hipGraph-style use: buffers allocated ONCE, three "replays" with different routing written into the same input
+    tensors; every intermediate the exchange allocates must have a routing-independent shape (a captured graph replays
+    fixed launches on fixed shapes), and each replay must give that replay's answer."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "sglang-fluentllm_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ep_torch_ops import TorchRowOps
+        from fluent_mi355.ep import AllToAll
+
+        E, K, HID, t = 8, 3, 64, 6
+        a2a = AllToAll(K, E, HID, t * world, None, row_ops=TorchRowOps())
+        x = torch.empty(t, HID, dtype=torch.bfloat16)
+        idx = torch.empty(t, K, dtype=torch.int32)
+        w = torch.empty(t, K)
+        ex = torch.empty(E // world + 1, dtype=torch.int32)
+        expert_x = torch.zeros(world * a2a.cap * K, HID, dtype=torch.bfloat16)      # the static row bound
+        out = torch.empty(t, HID, dtype=torch.bfloat16)
+        shapes = None
+        for it in range(3):
+            g = torch.Generator().manual_seed(1000 * it + rank)
+            x.copy_(torch.randn(t, HID, generator=g).to(torch.bfloat16))
+            if it == 1:      # skewed: everything to rank 0's experts
+                idx.copy_(torch.stack([torch.randperm(E // world, generator=g)[:K] for _ in range(t)]).to(torch.int32))
+            else:
+                idx.copy_(torch.stack([torch.randperm(E, generator=g)[:K] for _ in range(t)]).to(torch.int32))
+            w.copy_(torch.rand(t, K, generator=g))
+            a2a.dispatch(out_exclusive_sum=ex, out_expert_x=expert_x, dp_x=x, indices=idx, num_global_tokens=t * world)
+            now = [tuple(v.shape) if torch.is_tensor(v) else v for v in a2a._state]
+            assert shapes is None or shapes == now, (shapes, now)
+            shapes = now
+            y = torch.full_like(expert_x, float("nan"))
+            for le in range(E // world):
+                lo, hi = int(ex[le]), int(ex[le + 1])
+                y[lo:hi] = (expert_x[lo:hi].float() * (rank * (E // world) + le + 1)).to(torch.bfloat16)
+            a2a.combine(out_tokens=out, weights=w, expert_y=y, num_global_tokens=t * world)
+            ref = sum(w[:, k:k + 1] * (x.float() * (idx[:, k:k + 1].float() + 1)).to(torch.bfloat16).float() for k in range(K))
+            assert torch.allclose(out.float(), ref.to(torch.bfloat16).float(), atol=2e-2, rtol=2e-2), it
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ep_all_to_all_static_shape_replays_world2_gloo():
+    port = _free_port()
+    mp.spawn(_replay_worker, args=(2, port), nprocs=2, join=True)
