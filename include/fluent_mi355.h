@@ -155,6 +155,37 @@ int fl_dual_rmsnorm(void* ag, int64_t T, int D, int q_rank, int kv_rank, const v
                     float eps_q, float eps_kv, void* x_norm_out, void* quant_out, float* scale_out, int64_t s_stride_t,
                     int64_t s_stride_g, fl_stream_t stream);
 
+/* ---- C5/C6 one-shot: the exchange AND the fused epilogue in one kernel over peer-mapped (hipIpc) workspaces — replaces
+ * flashinfer.comm.trtllm_create_ipc_workspace_for_all_reduce_fusion + trtllm_allreduce_fusion / trtllm_reducescatter_fusion
+ * (srt/layers/flashinfer_comm_fusion.py:64-109 workspace, :286-401 C5, :404-513 C6) for token counts up to the workspace's
+ * max_tokens.  Every rank writes its rows into each destination's inbox over xGMI, raises per-row flags, and the
+ * workgroup owning a row reduces it in rank order (bit-identical on all ranks) + residual + RMSNorm (+ 1x128 fp8 quant).
+ * Protocol: csrc/comm_protocol.h.  Setup: create on every rank -> exchange the 64-byte handles (any transport) ->
+ * connect.  The epoch lives in device memory: launches may be captured in a hipGraph and replayed. ---- */
+int fl_comm_workspace_size(int world, int64_t max_tokens, int hidden, int64_t* bytes_out);
+int fl_comm_create(int rank, int world, int64_t max_tokens /*<= 1024*/, int hidden /*<= 8192*/, void** comm_out);
+int fl_comm_local_handle(void* comm, void* handle_out /*64 bytes: hipIpcMemHandle_t of this rank's workspace*/);
+int fl_comm_connect(void* comm, const void* handles /*world x 64 bytes in rank order; NULL allowed at world 1*/);
+int fl_comm_set_timeout(void* comm, double seconds /*budget of one flag wait; default 2 s*/);
+/* C5: all ranks pass in bf16 [T, H]; every rank gets sum (+ residual_in [T, H]) -> residual_out, RMSNorm -> norm_out,
+ * quant_out/scale_out optional (any may be NULL; gamma NULL = sum only into residual_out). */
+int fl_allreduce_fused(void* comm, const void* in, int64_t T, int H, const void* residual_in, const void* gamma, float eps,
+                       void* residual_out, void* norm_out, void* quant_out, float* scale_out, int64_t s_stride_t,
+                       int64_t s_stride_g, fl_stream_t stream);
+/* C6: in bf16 [T, H] on every rank; rank r gets its token slice (get_num_tokens_per_rank: the first T % world ranks own
+ * one more) of the sum; add_in / residual_in / outputs are [slice rows, H]. */
+int fl_reducescatter_fused(void* comm, const void* in, int64_t T, int H, const void* add_in, const void* residual_in,
+                           const void* gamma, float eps, void* residual_out, void* norm_out, void* quant_out, float* scale_out,
+                           int64_t s_stride_t, int64_t s_stride_g, fl_stream_t stream);
+int fl_comm_check(void* comm /*synchronises; FL_ERR_LAUNCH if a flag wait ever timed out*/);
+int fl_comm_destroy(void* comm);
+/* The same protocol on plain host memory (shared-memory workspaces of several processes): drives the CPU-side protocol
+ * test of the flag / epoch / parity logic.  Test infrastructure — nothing on the product path calls these. */
+int fl_comm_host_init(void* ws, int world, int64_t max_tokens, int hidden);
+int fl_comm_host_exchange(void* const* ws /*[world] workspaces as mapped in this process*/, int rank, int world, int64_t max_tokens,
+                          int hidden, int reduce_scatter, const uint16_t* in /*bf16 [T, H]*/, int64_t T, int H,
+                          float* out /*f32 [rows, H]: the sums*/, double timeout_s);
+
 /* ---- C1/C2: device side of eps.fast_ep.AllToAll.dispatch / combine (srt/layers/moe/dispatcher/fast_ep.py:45-51,
  * 73-78).  The exchange is one equal-split all-to-all per direction over RCCL (host: torch.distributed); these do the
  * integer / row work around it, sync-free with static shapes.  Rows are bf16 [*, hidden], hidden % 8 == 0. ---- */

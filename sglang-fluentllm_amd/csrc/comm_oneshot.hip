@@ -1,0 +1,362 @@
+// C5 / C6 as ONE kernel over peer-mapped buffers — the MI355X form of the reference's one-shot fused collectives
+// (flashinfer.comm.trtllm_allreduce_fusion / trtllm_reducescatter_fusion over the IPC workspace of
+// /root/reference/python/sglang/srt/layers/flashinfer_comm_fusion.py:64-109; call sites :286-401, :404-513; the same
+// transport idea as vllm's custom all-reduce, srt/distributed/device_communicators/custom_all_reduce.py:43-44,284-297).
+//
+// xGMI is a point-to-point mesh: for a decode step's few dozen token rows the exchange is latency-, not bandwidth-bound,
+// so every rank WRITES its rows straight into each destination's inbox over its own link (posted stores on all 7 links
+// at once, no ring, no second launch), raises a per-row flag, and the workgroup that owns a row spins on that row's
+// flags only — no grid-wide barrier, one workgroup per token row end to end:
+//     push row -> fence -> flags -> wait for the peers' flags of MY row -> sum in rank order (+ add_in, + residual) ->
+//     RMSNorm -> optional 1x128 e4m3 quantisation                      (row work: norm_row.h, same code as norm_fused.hip)
+// Protocol, layout, and why two buffer parities suffice: comm_protocol.h.  The workspace is allocated uncached
+// (fine-grained): a peer's stores must become visible to a kernel that is already running here.
+// A wait that exceeds its time budget sets the sticky error word and the kernel ends (fl_comm_check reports it): a lost
+// peer must not hang the GPU.
+#include <string.h>
+
+#include <chrono>
+#include <thread>
+
+#include "comm_protocol.h"
+#include "norm_row.h"
+
+namespace {
+
+constexpr int kMaxWorld = 16;
+constexpr long long kMaxOneShotTokens = 1024;   // every workgroup of the launch must be resident: they wait on each other's peers
+
+struct Peers {
+  uint8_t* ws[kMaxWorld];
+};
+
+struct FlComm {
+  int rank, world;
+  FlCommLayout L;
+  uint8_t* local;
+  uint8_t* peer[kMaxWorld];
+  bool opened[kMaxWorld];
+  bool connected;
+  double timeout_s;
+};
+
+__device__ __forceinline__ void store_flag(uint8_t* ws, const long long idx, const unsigned e) {
+  unsigned* f = reinterpret_cast<unsigned*>(ws + fl_comm_flags_offset()) + idx;
+  __hip_atomic_store(f, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// true = the flag arrived
+__device__ __forceinline__ bool wait_flag(uint8_t* ws, const long long idx, const unsigned e, const unsigned long long budget) {
+  unsigned* f = reinterpret_cast<unsigned*>(ws + fl_comm_flags_offset()) + idx;
+  const unsigned long long t0 = wall_clock64();   // constant 100 MHz
+  while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+    if (wall_clock64() - t0 > budget) return false;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return true;
+}
+
+// grid = T + 1 workgroups: block t < T owns token row t, block T keeps the ranks in step (the sync row)
+template <bool kRS>
+__global__ __launch_bounds__(256) void oneshot_kernel(const Peers peers, const int rank, const FlCommLayout L,
+                                                      const uint16_t* __restrict__ in, const long long T, const int H,
+                                                      const uint16_t* __restrict__ add_in, const uint16_t* __restrict__ residual_in,
+                                                      const uint16_t* __restrict__ gamma, const float eps,
+                                                      uint16_t* __restrict__ residual_out, uint16_t* __restrict__ norm_out,
+                                                      uint8_t* __restrict__ quant_out, float* __restrict__ scale_out,
+                                                      const long long ss_t, const long long ss_g,
+                                                      const unsigned long long budget) {
+  __shared__ float wsum[4];
+  __shared__ unsigned s_epoch;
+  __shared__ int s_fail;
+  uint8_t* me = peers.ws[rank];
+  FlCommState* st = reinterpret_cast<FlCommState*>(me);
+  const int tid = threadIdx.x;
+  const int W = L.world;
+  if (tid == 0) {
+    s_epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_fail = 0;
+  }
+  __syncthreads();
+  const unsigned e = s_epoch;
+  const int par = (int)(e & 1u);
+  const long long t = blockIdx.x;
+  bool consume = false;
+  long long row_l = 0;
+  if (t < T) {
+    // ---- push: this rank's row t into the inbox of its destination(s) ----
+    uint4 r[fl_norm::kRowChunks];
+#pragma unroll
+    for (int c = 0; c < fl_norm::kRowChunks; ++c) {
+      const int col = (c * 256 + tid) * 8;
+      r[c] = col < H ? *reinterpret_cast<const uint4*>(in + t * H + col) : make_uint4(0, 0, 0, 0);
+    }
+    const int owner = kRS ? fl_comm_owner(T, W, t) : 0;
+    const long long row_d = kRS ? t - fl_comm_slice_lo(T, W, owner) : t;
+    for (int p = kRS ? owner : 0; p < (kRS ? owner + 1 : W); ++p) {
+      uint16_t* dst = reinterpret_cast<uint16_t*>(peers.ws[p] + fl_comm_inbox_offset(L)) + fl_comm_inbox_row(L, par, rank, row_d);
+#pragma unroll
+      for (int c = 0; c < fl_norm::kRowChunks; ++c) {
+        const int col = (c * 256 + tid) * 8;
+        if (col < H) *reinterpret_cast<uint4*>(dst + col) = r[c];
+      }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (kRS) {
+      if (tid == 0) store_flag(peers.ws[owner], fl_comm_flag_index(L, par, rank, row_d), e);
+    } else if (tid < W) {
+      store_flag(peers.ws[tid], fl_comm_flag_index(L, par, rank, row_d), e);
+    }
+    // ---- wait: the owner of the row collects every source's copy ----
+    consume = !kRS || owner == rank;
+    row_l = row_d;
+    if (consume && tid < W && !wait_flag(me, fl_comm_flag_index(L, par, tid, row_l), e, budget)) s_fail = 1;
+  } else if (tid < W) {
+    store_flag(peers.ws[tid], fl_comm_flag_index(L, par, W, rank), e);
+    if (!wait_flag(me, fl_comm_flag_index(L, par, W, tid), e, budget)) s_fail = 1;
+  }
+  __syncthreads();
+  if (s_fail) {
+    if (tid == 0) __hip_atomic_store(&st->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if (consume) {
+    const uint16_t* xrow = reinterpret_cast<const uint16_t*>(me + fl_comm_inbox_offset(L)) + fl_comm_inbox_row(L, par, 0, row_l);
+    fl_norm::add_rmsnorm_row(xrow, W, L.max_tokens * (long long)L.hidden, add_in, residual_in, gamma, eps, row_l, H, residual_out,
+                             norm_out, quant_out, scale_out, ss_t, ss_g, wsum);
+  }
+  // ---- the last workgroup out advances the epoch (the next launch on this stream starts after this one has ended) ----
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    const unsigned old = atomicAdd(&st->arrive, 1u);
+    if (old == gridDim.x - 1) {
+      st->arrive = 0;
+      __threadfence();
+      __hip_atomic_store(&st->epoch, e + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+int launch(FlComm* c, bool rs, const void* in, int64_t T, int H, const void* add_in, const void* residual_in, const void* gamma,
+           float eps, void* residual_out, void* norm_out, void* quant_out, float* scale_out, int64_t ss_t, int64_t ss_g,
+           fl_stream_t stream) {
+  FL_CHECK_ARG(c != nullptr && c->connected, "one-shot comm: not connected (fl_comm_connect)");
+  FL_CHECK_ARG(T >= 0 && T <= c->L.max_tokens * (rs ? c->world : 1) && T <= kMaxOneShotTokens,
+               "one-shot comm: T=%lld exceeds the workspace (max_tokens %lld)", (long long)T, c->L.max_tokens);
+  FL_CHECK_ARG(H > 0 && H % 8 == 0 && H <= c->L.hidden && H <= fl_norm::kMaxChunks * 512, "one-shot comm: H=%d (workspace hidden %d)", H,
+               c->L.hidden);
+  FL_CHECK_ARG(in != nullptr || T == 0, "one-shot comm: null input");
+  FL_CHECK_ARG(gamma != nullptr || (norm_out == nullptr && quant_out == nullptr), "one-shot comm: norm needs gamma");
+  FL_CHECK_ARG(quant_out == nullptr || (scale_out != nullptr && H % 128 == 0), "one-shot comm: quant needs scales, H %% 128 == 0");
+  if (rs) {   // a slice must fit the per-source inbox rows
+    FL_CHECK_ARG((T + c->world - 1) / c->world <= c->L.max_tokens, "one-shot comm: token slice exceeds max_tokens");
+  }
+  Peers peers;
+  for (int p = 0; p < kMaxWorld; ++p) peers.ws[p] = p < c->world ? c->peer[p] : nullptr;
+  const unsigned long long budget = (unsigned long long)(c->timeout_s * 1e8);
+  const dim3 grid((unsigned)T + 1);
+  if (rs)
+    oneshot_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(
+        peers, c->rank, c->L, (const uint16_t*)in, T, H, (const uint16_t*)add_in, (const uint16_t*)residual_in, (const uint16_t*)gamma,
+        eps, (uint16_t*)residual_out, (uint16_t*)norm_out, (uint8_t*)quant_out, scale_out, ss_t, ss_g, budget);
+  else
+    oneshot_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(
+        peers, c->rank, c->L, (const uint16_t*)in, T, H, (const uint16_t*)add_in, (const uint16_t*)residual_in, (const uint16_t*)gamma,
+        eps, (uint16_t*)residual_out, (uint16_t*)norm_out, (uint8_t*)quant_out, scale_out, ss_t, ss_g, budget);
+  FL_CHECK_LAUNCH("oneshot_kernel");
+  return FL_OK;
+}
+
+}  // namespace
+
+extern "C" int fl_comm_workspace_size(int world, int64_t max_tokens, int hidden, int64_t* bytes_out) {
+  FL_CHECK_ARG(world >= 1 && world <= kMaxWorld && max_tokens >= 1 && hidden >= 8 && hidden % 8 == 0 && bytes_out,
+               "fl_comm_workspace_size: bad arguments");
+  *bytes_out = fl_comm_workspace_bytes(FlCommLayout{world, max_tokens, hidden});
+  return FL_OK;
+}
+
+extern "C" int fl_comm_create(int rank, int world, int64_t max_tokens, int hidden, void** comm_out) {
+  FL_CHECK_ARG(comm_out && world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world, "fl_comm_create: rank %d of %d", rank, world);
+  FL_CHECK_ARG(max_tokens >= 1 && max_tokens <= kMaxOneShotTokens && hidden >= 8 && hidden % 8 == 0 && hidden <= 8192,
+               "fl_comm_create: max_tokens %lld (<= %lld), hidden %d", (long long)max_tokens, kMaxOneShotTokens, hidden);
+  FlComm* c = new FlComm();
+  c->rank = rank;
+  c->world = world;
+  c->L = FlCommLayout{world, max_tokens, hidden};
+  c->connected = false;
+  c->timeout_s = 2.0;
+  for (int p = 0; p < kMaxWorld; ++p) { c->peer[p] = nullptr; c->opened[p] = false; }
+  const size_t bytes = (size_t)fl_comm_workspace_bytes(c->L);
+  void* ptr = nullptr;
+  hipError_t err = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocUncached);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    err = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocFinegrained);
+  }
+  if (err != hipSuccess) {
+    delete c;
+    fl_set_error("fl_comm_create: cannot allocate %zu bytes of fine-grained device memory: %s", bytes, hipGetErrorString(err));
+    return FL_ERR_LAUNCH;
+  }
+  c->local = (uint8_t*)ptr;
+  FlCommState st{};
+  st.epoch = 1;
+  if (hipMemset(ptr, 0, bytes) != hipSuccess || hipMemcpy(ptr, &st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(ptr);
+    delete c;
+    fl_set_error("fl_comm_create: cannot initialise the workspace");
+    return FL_ERR_LAUNCH;
+  }
+  c->peer[rank] = c->local;
+  if (world == 1) c->connected = true;
+  *comm_out = c;
+  return FL_OK;
+}
+
+extern "C" int fl_comm_local_handle(void* comm, void* handle_out /* 64 bytes */) {
+  FlComm* c = (FlComm*)comm;
+  FL_CHECK_ARG(c && handle_out, "fl_comm_local_handle: null argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+  hipIpcMemHandle_t h;
+  const hipError_t err = hipIpcGetMemHandle(&h, c->local);
+  if (err != hipSuccess) {
+    fl_set_error("fl_comm_local_handle: hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 needed on this driver)", hipGetErrorString(err));
+    return FL_ERR_LAUNCH;
+  }
+  memcpy(handle_out, &h, 64);
+  return FL_OK;
+}
+
+extern "C" int fl_comm_connect(void* comm, const void* handles /* world x 64 bytes, rank order; may be null at world 1 */) {
+  FlComm* c = (FlComm*)comm;
+  FL_CHECK_ARG(c && (handles || c->world == 1), "fl_comm_connect: null argument");
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank || c->opened[p]) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const uint8_t*)handles + 64 * p, 64);
+    void* ptr = nullptr;
+    const hipError_t err = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (err != hipSuccess) {
+      fl_set_error("fl_comm_connect: hipIpcOpenMemHandle(rank %d): %s", p, hipGetErrorString(err));
+      return FL_ERR_LAUNCH;
+    }
+    c->peer[p] = (uint8_t*)ptr;
+    c->opened[p] = true;
+  }
+  c->connected = true;
+  return FL_OK;
+}
+
+extern "C" int fl_comm_set_timeout(void* comm, double seconds) {
+  FlComm* c = (FlComm*)comm;
+  FL_CHECK_ARG(c && seconds > 0 && seconds <= 600, "fl_comm_set_timeout: bad arguments");
+  c->timeout_s = seconds;
+  return FL_OK;
+}
+
+extern "C" int fl_allreduce_fused(void* comm, const void* in, int64_t T, int H, const void* residual_in, const void* gamma, float eps,
+                                  void* residual_out, void* norm_out, void* quant_out, float* scale_out, int64_t s_stride_t,
+                                  int64_t s_stride_g, fl_stream_t stream) {
+  return launch((FlComm*)comm, false, in, T, H, nullptr, residual_in, gamma, eps, residual_out, norm_out, quant_out, scale_out,
+                s_stride_t, s_stride_g, stream);
+}
+
+extern "C" int fl_reducescatter_fused(void* comm, const void* in, int64_t T, int H, const void* add_in, const void* residual_in,
+                                      const void* gamma, float eps, void* residual_out, void* norm_out, void* quant_out,
+                                      float* scale_out, int64_t s_stride_t, int64_t s_stride_g, fl_stream_t stream) {
+  return launch((FlComm*)comm, true, in, T, H, add_in, residual_in, gamma, eps, residual_out, norm_out, quant_out, scale_out,
+                s_stride_t, s_stride_g, stream);
+}
+
+extern "C" int fl_comm_check(void* comm) {   // synchronises the device: not for the hot path
+  FlComm* c = (FlComm*)comm;
+  FL_CHECK_ARG(c, "fl_comm_check: null argument");
+  FlCommState st;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&st, c->local, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) {
+    fl_set_error("fl_comm_check: device error: %s", hipGetErrorString(hipGetLastError()));
+    return FL_ERR_LAUNCH;
+  }
+  if (st.error != 0) {
+    fl_set_error("one-shot comm: a wait for a peer's flag timed out (rank %d of %d, epoch %u)", c->rank, c->world, st.epoch);
+    return FL_ERR_LAUNCH;
+  }
+  return FL_OK;
+}
+
+extern "C" int fl_comm_destroy(void* comm) {
+  FlComm* c = (FlComm*)comm;
+  if (!c) return FL_OK;
+  (void)hipDeviceSynchronize();
+  for (int p = 0; p < c->world; ++p)
+    if (c->opened[p]) (void)hipIpcCloseMemHandle(c->peer[p]);
+  (void)hipFree(c->local);
+  delete c;
+  return FL_OK;
+}
+
+// ---- the same protocol on plain host memory: what the CPU-side multi-process protocol test drives (tests/ only; nothing
+//      on the product path calls these).  `ws[p]` = rank p's workspace as mapped in THIS process (shared memory). ----
+extern "C" int fl_comm_host_init(void* ws, int world, int64_t max_tokens, int hidden) {
+  FL_CHECK_ARG(ws && world >= 1 && world <= kMaxWorld, "fl_comm_host_init: bad arguments");
+  const FlCommLayout L{world, max_tokens, hidden};
+  memset(ws, 0, (size_t)fl_comm_workspace_bytes(L));
+  reinterpret_cast<FlCommState*>(ws)->epoch = 1;
+  return FL_OK;
+}
+
+extern "C" int fl_comm_host_exchange(void* const* ws, int rank, int world, int64_t max_tokens, int hidden, int reduce_scatter,
+                                     const uint16_t* in /*bf16 [T, H]*/, int64_t T, int H, float* out /*f32 [rows, H]*/,
+                                     double timeout_s) {
+  FL_CHECK_ARG(ws && rank >= 0 && rank < world && world <= kMaxWorld && H <= hidden && out, "fl_comm_host_exchange: bad arguments");
+  const FlCommLayout L{world, max_tokens, hidden};
+  uint8_t* me = (uint8_t*)ws[rank];
+  FlCommState* st = reinterpret_cast<FlCommState*>(me);
+  const unsigned e = __atomic_load_n(&st->epoch, __ATOMIC_ACQUIRE);
+  const int par = (int)(e & 1u);
+  auto flag = [&](int p, long long idx) { return reinterpret_cast<unsigned*>((uint8_t*)ws[p] + fl_comm_flags_offset()) + idx; };
+  auto wait = [&](long long idx) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (__atomic_load_n(flag(rank, idx), __ATOMIC_ACQUIRE) != e) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+      std::this_thread::yield();
+    }
+    return true;
+  };
+  for (long long t = 0; t < T; ++t) {   // push + flags, row by row (a device workgroup per row)
+    const int owner = reduce_scatter ? fl_comm_owner(T, world, t) : 0;
+    const long long row_d = reduce_scatter ? t - fl_comm_slice_lo(T, world, owner) : t;
+    for (int p = reduce_scatter ? owner : 0; p < (reduce_scatter ? owner + 1 : world); ++p) {
+      uint16_t* dst = reinterpret_cast<uint16_t*>((uint8_t*)ws[p] + fl_comm_inbox_offset(L)) + fl_comm_inbox_row(L, par, rank, row_d);
+      memcpy(dst, in + t * H, (size_t)H * 2);
+      __atomic_store_n(flag(p, fl_comm_flag_index(L, par, rank, row_d)), e, __ATOMIC_RELEASE);
+    }
+  }
+  for (int p = 0; p < world; ++p) __atomic_store_n(flag(p, fl_comm_flag_index(L, par, world, rank)), e, __ATOMIC_RELEASE);
+  bool ok = true;
+  for (int p = 0; p < world && ok; ++p) ok = wait(fl_comm_flag_index(L, par, world, p));
+  const long long lo = reduce_scatter ? fl_comm_slice_lo(T, world, rank) : 0;
+  const long long hi = reduce_scatter ? fl_comm_slice_lo(T, world, rank + 1) : T;
+  for (long long r = 0; r < hi - lo && ok; ++r) {
+    for (int s = 0; s < world && ok; ++s) ok = wait(fl_comm_flag_index(L, par, s, r));
+    if (!ok) break;
+    for (int col = 0; col < H; ++col) {
+      float acc = 0.f;
+      for (int s = 0; s < world; ++s) {
+        const uint16_t v = (reinterpret_cast<const uint16_t*>(me + fl_comm_inbox_offset(L)) + fl_comm_inbox_row(L, par, s, r))[col];
+        uint32_t bits = (uint32_t)v << 16;
+        float f;
+        memcpy(&f, &bits, 4);
+        acc += f;
+      }
+      out[r * H + col] = acc;
+    }
+  }
+  if (!ok) {
+    st->error = 1;
+    fl_set_error("fl_comm_host_exchange: rank %d timed out waiting for a flag at epoch %u", rank, e);
+    return FL_ERR_LAUNCH;
+  }
+  __atomic_store_n(&st->epoch, e + 1u, __ATOMIC_RELEASE);
+  return FL_OK;
+}

@@ -6,8 +6,12 @@ xGMI is a point-to-point mesh (7 links per GPU): the natural one-shot exchange i
 receives its peers' pieces directly (all_gather / all_to_all_single with the deterministic uneven token split of
 `get_num_tokens_per_rank`, flashinfer_comm_fusion.py:237-244), followed by ONE fused HIP kernel that reduces the received
 pieces and applies add_in + residual + RMSNorm (+ 1x128 FP8 block quantisation) — `fl_fused_add_rmsnorm` /
-`fl_dual_rmsnorm` (csrc/norm_fused.hip).  No IPC workspace is needed: the `workspace` objects only carry the process
-group.  Semantics that the (absent) third-party module leaves implicit are taken from the call sites and stated below.
+`fl_dual_rmsnorm` (csrc/norm_fused.hip).  For the decode regime (token counts up to the workspace's capacity) C5 and C6
+take the ONE-SHOT route instead: a peer-mapped (hipIpc) workspace per rank, created with the workspace object, into which
+the peers write their rows over xGMI, and a single kernel that pushes, waits on per-row flags and applies the fused
+epilogue — no RCCL call, one launch (`fluent_mi355/oneshot.py`, csrc/comm_oneshot.hip; FLUENT_ONESHOT=0 disables, the
+RCCL route then serves every size).  Both routes sum the pieces in rank order and share the epilogue code: their results are
+bit-identical.  Semantics that the (absent) third-party module leaves implicit are taken from the call sites and stated below.
 
 `norm_ops` exists so that the multi-process HOST logic can be exercised on CPU tensors with the gloo backend (tests inject a
 torch implementation); the product default is the HIP one and there is no automatic fallback."""
@@ -15,6 +19,7 @@ from __future__ import annotations
 
 import ctypes
 import enum
+import os
 from typing import Optional
 
 import torch
@@ -110,10 +115,12 @@ def _ops():
 
 
 class _Workspace:
-    """What `workspace_ptrs` resolves to: the process group of the exchange (nothing is IPC-mapped on this design)."""
+    """What `workspace_ptrs` resolves to: the process group of the RCCL route and, when it could be set up, the one-shot
+    peer-mapped communicator (`oneshot`, fluent_mi355/oneshot.py)."""
 
     def __init__(self, rank, world_size, group):
         self.rank, self.world_size, self.group = rank, world_size, group
+        self.oneshot = None
 
 
 _registry = {}
@@ -143,12 +150,25 @@ def _device_of_group(group):
 
 def trtllm_create_ipc_workspace_for_all_reduce_fusion(rank, world_size, max_token_num, hidden_dim, group=None,
                                                       use_fp32_lamport=False):
-    """flashinfer_comm_fusion.py:86-93 -> (ipc_handles, workspace_tensor)."""
-    return _register(rank, world_size, group, _device_of_group(group) if dist.is_initialized() else None)
+    """flashinfer_comm_fusion.py:86-93 -> (ipc_handles, workspace_tensor).  With a HIP device and an RCCL group of more than
+    one rank this also allocates the rank's one-shot workspace and maps the peers' (a collective call, like the
+    reference's: every rank of the group must make it).  FLUENT_ONESHOT=0: never; =1: also at world 1 (tests)."""
+    handles, tensor = _register(rank, world_size, group, _device_of_group(group) if dist.is_initialized() else None)
+    want = os.environ.get("FLUENT_ONESHOT", "auto")
+    multi = dist.is_initialized() and world_size > 1 and dist.get_world_size(group) == world_size and dist.get_backend(group) == "nccl"
+    if want != "0" and torch.cuda.is_available() and (multi or want == "1"):
+        from .oneshot import OneShotComm
+
+        handles[0].oneshot = OneShotComm(rank if multi else 0, world_size if multi else 1, max_token_num, hidden_dim, group=group)
+    return handles, tensor
 
 
 def trtllm_destroy_ipc_workspace_for_all_reduce_fusion(ipc_handles, group=None):
     """flashinfer_comm_fusion.py:115-117."""
+    for ws in ipc_handles or []:
+        if getattr(ws, "oneshot", None) is not None:
+            ws.oneshot.close()
+            ws.oneshot = None
     return None
 
 
@@ -221,6 +241,17 @@ def trtllm_allreduce_fusion(allreduce_in, world_size, world_rank, token_num, hid
     ws = _resolve(workspace_ptrs)
     W = _world(ws)
     T, H = allreduce_in.shape
+    only_sum = pattern_code is not None and int(pattern_code) == int(AllReduceFusionPattern.kAllReduce)
+    osc = ws.oneshot
+    if (osc is not None and use_oneshot is not False and osc.world == W and osc.fits(T, H) and not residual_reduce_scattered
+            and partial_norm_out is None and (only_sum or allreduce_out is None)):
+        # one launch: push over xGMI, per-row flags, fused epilogue (csrc/comm_oneshot.hip)
+        x = allreduce_in.contiguous()
+        if only_sum:
+            osc.allreduce_fused(x, residual_out=allreduce_out)
+        else:
+            osc.allreduce_fused(x, residual_in, rms_gamma, rms_eps, residual_out, norm_out, quant_out, scale_out)
+        return
     counts = get_num_tokens_per_rank(W, T)
     lo = sum(counts[:world_rank]) if W > 1 else 0
     hi = lo + (counts[world_rank] if W > 1 else T)
@@ -254,6 +285,16 @@ def trtllm_reducescatter_fusion(reducescatter_in, world_size, world_rank, token_
     ws = _resolve(workspace_ptrs)
     W = _world(ws)
     T, H = reducescatter_in.shape
+    only_sum = pattern_code is not None and int(pattern_code) == int(ReduceScatterFusionPattern.kReduceScatter)
+    osc = ws.oneshot
+    if (osc is not None and use_oneshot is not False and osc.world == W and osc.fits(T, H, reduce_scatter=True)
+            and (only_sum or reducescatter_out is None)):
+        x = reducescatter_in.contiguous()
+        if only_sum:
+            osc.reducescatter_fused(x, residual_out=reducescatter_out)
+        else:
+            osc.reducescatter_fused(x, add_in, residual_in, rms_gamma, rms_eps, residual_out, norm_out, quant_out, scale_out)
+        return
     counts = get_num_tokens_per_rank(W, T)
     mine = counts[world_rank] if W > 1 else T
     if W == 1:

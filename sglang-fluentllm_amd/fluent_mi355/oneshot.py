@@ -1,0 +1,94 @@
+"""One-shot peer-mapped fused collectives (C5/C6) — host side of csrc/comm_oneshot.hip.
+
+Replaces the IPC workspace + one-shot kernels of the reference's flashinfer.comm
+(srt/layers/flashinfer_comm_fusion.py:64-109 workspace creation, :286-401 all-reduce fusion, :404-513 reduce-scatter
+fusion): every rank allocates one uncached workspace, the 64-byte hipIpc handles are exchanged once through
+torch.distributed (`all_gather_object`: setup only, never on the hot path), every rank maps its peers' workspaces, and
+from then on an all-reduce / reduce-scatter + residual + RMSNorm (+ 1x128 fp8 quant) is ONE kernel launch with no RCCL
+call.  `fluent_mi355.comm` routes to it for token counts up to `max_tokens` (env FLUENT_ONESHOT=0 disables)."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from ._lib import check, lib, stream_ptr
+
+MAX_ONESHOT_TOKENS = 1024
+
+_vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+lib.fl_comm_create.argtypes = [_i32, _i32, _i64, _i32, ctypes.POINTER(_vp)]
+lib.fl_comm_local_handle.argtypes = [_vp, _vp]
+lib.fl_comm_connect.argtypes = [_vp, _vp]
+lib.fl_comm_set_timeout.argtypes = [_vp, ctypes.c_double]
+lib.fl_allreduce_fused.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i64, _vp]
+lib.fl_reducescatter_fused.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i64, _vp]
+lib.fl_comm_check.argtypes = [_vp]
+lib.fl_comm_destroy.argtypes = [_vp]
+for _n in ("fl_comm_create", "fl_comm_local_handle", "fl_comm_connect", "fl_comm_set_timeout", "fl_allreduce_fused",
+           "fl_reducescatter_fused", "fl_comm_check", "fl_comm_destroy"):
+    getattr(lib, _n).restype = _i32
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class OneShotComm:
+    """One rank's end of the peer-mapped exchange.  `exchange` maps this rank's 64-byte handle to the list of all ranks'
+    handles in rank order (default: all_gather_object on `group`)."""
+
+    def __init__(self, rank, world, max_tokens, hidden, group=None, exchange=None, timeout_s=None):
+        self.rank, self.world, self.hidden = int(rank), int(world), int(hidden)
+        self.max_tokens = min(int(max_tokens), MAX_ONESHOT_TOKENS)
+        h = _vp()
+        check(lib.fl_comm_create(self.rank, self.world, self.max_tokens, self.hidden, ctypes.byref(h)), "fl_comm_create")
+        self._h = h
+        if self.world > 1:
+            mine = ctypes.create_string_buffer(64)
+            check(lib.fl_comm_local_handle(self._h, ctypes.cast(mine, _vp)), "fl_comm_local_handle")
+            if exchange is None:
+                def exchange(b):
+                    out = [None] * self.world
+                    dist.all_gather_object(out, b, group=group)
+                    return out
+            handles = exchange(bytes(mine.raw))
+            if len(handles) != self.world or any(len(x) != 64 for x in handles):
+                raise RuntimeError("one-shot comm: the handle exchange must return one 64-byte handle per rank")
+            blob = ctypes.create_string_buffer(b"".join(handles), 64 * self.world)
+            check(lib.fl_comm_connect(self._h, ctypes.cast(blob, _vp)), "fl_comm_connect")
+        if timeout_s is not None:
+            check(lib.fl_comm_set_timeout(self._h, float(timeout_s)), "fl_comm_set_timeout")
+
+    def fits(self, tokens, hidden, reduce_scatter=False):
+        per = -(-tokens // self.world) if reduce_scatter else tokens
+        return tokens <= MAX_ONESHOT_TOKENS and per <= self.max_tokens and hidden <= self.hidden and hidden % 8 == 0
+
+    @staticmethod
+    def _strides(scale_out):
+        return (0, 0) if scale_out is None else (scale_out.stride(0), scale_out.stride(1))
+
+    def allreduce_fused(self, x, residual_in=None, gamma=None, eps=1e-6, residual_out=None, norm_out=None, quant_out=None,
+                        scale_out=None):
+        T, H = x.shape
+        st, sg = self._strides(scale_out)
+        check(lib.fl_allreduce_fused(self._h, x.data_ptr(), T, H, _p(residual_in), _p(gamma), float(eps), _p(residual_out),
+                                     _p(norm_out), _p(quant_out), _p(scale_out), st, sg, stream_ptr(x.device)), "fl_allreduce_fused")
+
+    def reducescatter_fused(self, x, add_in=None, residual_in=None, gamma=None, eps=1e-6, residual_out=None, norm_out=None,
+                            quant_out=None, scale_out=None):
+        T, H = x.shape
+        st, sg = self._strides(scale_out)
+        check(lib.fl_reducescatter_fused(self._h, x.data_ptr(), T, H, _p(add_in), _p(residual_in), _p(gamma), float(eps),
+                                         _p(residual_out), _p(norm_out), _p(quant_out), _p(scale_out), st, sg, stream_ptr(x.device)),
+              "fl_reducescatter_fused")
+
+    def check(self):
+        """synchronises; raises if a flag wait ever timed out (a peer died or issued a different sequence of operations)"""
+        check(lib.fl_comm_check(self._h), "fl_comm_check")
+
+    def close(self):
+        if self._h is not None:
+            lib.fl_comm_destroy(self._h)
+            self._h = None

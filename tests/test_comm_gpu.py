@@ -136,3 +136,125 @@ def test_tpdp_convertor_world1_and_sum_kernel():
     HipNormOps().add_rmsnorm(pieces.to(dev()), None, None, None, 0.0, out, None, None, None)
     torch.cuda.synchronize()
     assert ulp_close(out, pieces.float().sum(0).to(torch.bfloat16), frac=2e-2)
+
+
+DEV = torch.device("cuda:0")
+
+
+def _oneshot(world_hidden=7168, max_tokens=128):
+    from fluent_mi355.oneshot import OneShotComm
+    return OneShotComm(0, 1, max_tokens, world_hidden)
+
+
+@pytest.mark.parametrize("T,H", [(1, 7168), (37, 7168), (128, 2048), (5, 136)])
+def test_oneshot_world1_is_bit_identical_to_the_fused_kernel(T, H):
+    """C5/C6 one-shot route (csrc/comm_oneshot.hip: push -> flags -> wait -> fused epilogue in ONE kernel) at world 1 against
+    the RCCL route's kernel on the same rows: same epilogue code, same summation order -> identical bits; plus the golden
+    vectors of RMSNorm.forward_native through the public entry point below."""
+    from fluent_mi355.comm import HipNormOps
+    ops, c = HipNormOps(), _oneshot()
+    g = torch.Generator().manual_seed(T * 31 + H)
+    x = torch.randn(T, H, generator=g).to(torch.bfloat16).to(DEV)
+    add = torch.randn(T, H, generator=g).to(torch.bfloat16).to(DEV)
+    res = torch.randn(T, H, generator=g).to(torch.bfloat16).to(DEV)
+    gamma = torch.rand(H, generator=g).to(torch.bfloat16).to(DEV)
+    quant = H % 128 == 0
+
+    def outs():
+        return (torch.empty(T, H, dtype=torch.bfloat16, device=DEV), torch.empty(T, H, dtype=torch.bfloat16, device=DEV),
+                torch.empty(T, H, dtype=torch.float8_e4m3fn, device=DEV) if quant else None,
+                torch.empty(T, H // 128, dtype=torch.float32, device=DEV) if quant else None)
+    e = outs()
+    ops.add_rmsnorm(x.unsqueeze(0), None, res, gamma, 1e-6, *e)
+    o = outs()
+    c.allreduce_fused(x, res, gamma, 1e-6, *o)
+    e2 = outs()
+    ops.add_rmsnorm(x.unsqueeze(0), add, res, gamma, 1e-6, *e2)
+    o2 = outs()
+    c.reducescatter_fused(x, add, res, gamma, 1e-6, *o2)
+    s_e, s_o = torch.empty(T, H, dtype=torch.bfloat16, device=DEV), torch.empty(T, H, dtype=torch.bfloat16, device=DEV)
+    ops.add_rmsnorm(x.unsqueeze(0), None, None, None, 0.0, s_e, None, None, None)
+    c.allreduce_fused(x, residual_out=s_o)
+    c.check()
+    for a, b in list(zip(e, o)) + list(zip(e2, o2)) + [(s_e, s_o)]:
+        if a is not None:
+            assert torch.equal(a.view(torch.uint8) if a.dtype == torch.float8_e4m3fn else a, b.view(torch.uint8) if b.dtype == torch.float8_e4m3fn else b)
+    c.close()
+
+
+def test_oneshot_replays_in_a_hipgraph_and_rejects_oversize():
+    """the epoch lives in device memory: a captured launch replays (different data each replay); sizes beyond the workspace
+    are refused loudly"""
+    from fluent_mi355.comm import HipNormOps
+    ops, c = HipNormOps(), _oneshot(2048, 32)
+    T, H = 32, 2048
+    x = torch.zeros(T, H, dtype=torch.bfloat16, device=DEV)
+    res = torch.zeros(T, H, dtype=torch.bfloat16, device=DEV)
+    gamma = torch.ones(H, dtype=torch.bfloat16, device=DEV)
+    o_res, o_norm = torch.empty_like(x), torch.empty_like(x)
+    c.allreduce_fused(x, res, gamma, 1e-6, o_res, o_norm)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        c.allreduce_fused(x, res, gamma, 1e-6, o_res, o_norm)
+    torch.cuda.current_stream().wait_stream(s)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        c.allreduce_fused(x, res, gamma, 1e-6, o_res, o_norm)
+        c.reducescatter_fused(o_norm, None, None, gamma, 1e-6, None, o_res)      # two dependent operations per replay
+    for it in range(4):
+        g = torch.Generator().manual_seed(it)
+        x.copy_(torch.randn(T, H, generator=g).to(torch.bfloat16))
+        res.copy_(torch.randn(T, H, generator=g).to(torch.bfloat16))
+        gr.replay()
+        e_res, e_norm, e2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        ops.add_rmsnorm(x.unsqueeze(0), None, res, gamma, 1e-6, e_res, e_norm, None, None)
+        ops.add_rmsnorm(e_norm.unsqueeze(0), None, None, gamma, 1e-6, None, e2, None, None)
+        assert torch.equal(o_norm, e_norm) and torch.equal(o_res, e2), it
+    c.check()
+    with pytest.raises(RuntimeError, match="exceeds"):
+        c.allreduce_fused(torch.zeros(33, H, dtype=torch.bfloat16, device=DEV), res, gamma, 1e-6, o_res, o_norm)
+    c.close()
+
+
+def test_public_fusion_entry_points_take_the_oneshot_route_when_enabled(monkeypatch):
+    """flashinfer.comm.trtllm_allreduce_fusion / trtllm_reducescatter_fusion with FLUENT_ONESHOT=1 (one-shot also at world 1)
+    give the bits of the default route"""
+    import flashinfer.comm as comm
+    T, H = 24, 7168
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(T, H, generator=g).to(torch.bfloat16).to(DEV)
+    res = torch.randn(T, H, generator=g).to(torch.bfloat16).to(DEV)
+    gamma = torch.rand(H, generator=g).to(torch.bfloat16).to(DEV)
+    got = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("FLUENT_ONESHOT", flag)
+        handles, wsp = comm.trtllm_create_ipc_workspace_for_all_reduce_fusion(0, 1, 64, H)
+        assert (handles[0].oneshot is not None) == (flag == "1")
+        r, n = torch.empty_like(x), torch.empty_like(x)
+        q, sc = torch.empty(T, H, dtype=torch.float8_e4m3fn, device=DEV), torch.empty(T, H // 128, dtype=torch.float32, device=DEV)
+        comm.trtllm_allreduce_fusion(allreduce_in=x, world_size=1, world_rank=0, token_num=T, hidden_dim=H, workspace_ptrs=wsp,
+                                     pattern_code=comm.AllReduceFusionPattern.kARResidualRMSNormFP8BlockWiseQuant, residual_in=res,
+                                     residual_out=r, norm_out=n, quant_out=q, scale_out=sc, rms_gamma=gamma, rms_eps=1e-6)
+        r2, n2 = torch.empty_like(x), torch.empty_like(x)
+        comm.trtllm_reducescatter_fusion(reducescatter_in=x, world_size=1, world_rank=0, token_num=T, hidden_dim=H, workspace_ptrs=wsp,
+                                         num_token_current_rank=T, pattern_code=comm.ReduceScatterFusionPattern.kRSResidualRMSNorm,
+                                         residual_in=res, residual_out=r2, norm_out=n2, rms_gamma=gamma, rms_eps=1e-6)
+        torch.cuda.synchronize()
+        got.append([r, n, q.view(torch.uint8), sc, r2, n2])
+        comm.trtllm_destroy_ipc_workspace_for_all_reduce_fusion(handles)
+    for a, b in zip(*got):
+        assert torch.equal(a, b)
+
+
+def test_oneshot_two_processes_on_one_gpu_hipipc():
+    """The multi-rank kernel path on hardware, as far as a one-GPU box allows: two PROCESSES, each with its own workspace,
+    map each other's through hipIpc and run fused all-reduces / reduce-scatters against each other (real cross-process
+    flag waits; handles travel over gloo).  Bit-identical to the RCCL route's kernel on the stacked inputs.  Every wait is
+    time-bounded: a co-scheduling problem would be an error, not a hang."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "oneshot_two_procs.py"), "2"], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("parity OK") == 2, r.stdout[-2000:]

@@ -1,0 +1,59 @@
+"""GPU box: the one-shot peer-mapped exchange between TWO PROCESSES on ONE GPU (the boxes here have a single GPU: this is
+the closest hardware run of the multi-rank kernel path — real hipIpc mapping, real cross-process flag waits; what it
+cannot show is xGMI).  Handles travel over a gloo group.  Every wait is time-bounded, so a scheduling problem shows up as
+an error, not a hang.  usage: python tools/oneshot_two_procs.py [world]"""
+import os, sys, socket
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sglang-fluentllm_amd"))
+import torch, torch.distributed as dist, torch.multiprocessing as mp
+
+
+def worker(rank, world, port, T, H, iters):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from fluent_mi355.oneshot import OneShotComm
+    from fluent_mi355.comm import HipNormOps, get_num_tokens_per_rank
+    c = OneShotComm(rank, world, 64, H, timeout_s=5.0)
+    ops = HipNormOps()
+    ok = True
+    for it in range(iters):
+        g = torch.Generator().manual_seed(100 * it)
+        xs = [torch.randn(T, H, generator=g).to(torch.bfloat16) for _ in range(world)]      # every rank knows all inputs
+        res = torch.randn(T, H, generator=g).to(torch.bfloat16).to(dev)
+        gamma = torch.rand(H, generator=g).to(torch.bfloat16).to(dev)
+        pieces = torch.stack(xs).to(dev)
+        # expected: the RCCL route's kernel on the stacked pieces
+        e_res, e_norm = torch.empty(T, H, dtype=torch.bfloat16, device=dev), torch.empty(T, H, dtype=torch.bfloat16, device=dev)
+        ops.add_rmsnorm(pieces, None, res, gamma, 1e-6, e_res, e_norm, None, None)
+        o_res, o_norm = torch.empty_like(e_res), torch.empty_like(e_norm)
+        c.allreduce_fused(xs[rank].to(dev), res, gamma, 1e-6, o_res, o_norm)
+        counts = get_num_tokens_per_rank(world, T)
+        lo = sum(counts[:rank]); hi = lo + counts[rank]
+        r_res, r_norm = torch.empty(hi - lo, H, dtype=torch.bfloat16, device=dev), torch.empty(hi - lo, H, dtype=torch.bfloat16, device=dev)
+        c.reducescatter_fused(xs[rank].to(dev), None, res[lo:hi].contiguous(), gamma, 1e-6, r_res, r_norm)
+        c.check()
+        ok &= torch.equal(o_res, e_res) and torch.equal(o_norm, e_norm) and torch.equal(r_res, e_res[lo:hi]) and torch.equal(r_norm, e_norm[lo:hi])
+    # latency of the fused all-reduce (graph of 20 launches)
+    x = xs[rank].to(dev)
+    for _ in range(3): c.allreduce_fused(x, res, gamma, 1e-6, o_res, o_norm)
+    torch.cuda.synchronize(); dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): c.allreduce_fused(x, res, gamma, 1e-6, o_res, o_norm)
+    e1.record(); torch.cuda.synchronize()
+    c.check()
+    print(f"rank {rank}/{world}: T={T} H={H} parity {'OK' if ok else 'MISMATCH'} over {iters} iterations; fused all-reduce {e0.elapsed_time(e1) / 50 * 1e3:.1f} us/op (processes sharing one GPU)", flush=True)
+    dist.barrier()
+    c.close()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
+if __name__ == "__main__":
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mp.spawn(worker, args=(world, port, 48, 7168, 5), nprocs=world, join=True)
