@@ -37,7 +37,8 @@ constexpr int kScratchPerWave = 3 * 32 * 4;                        // {ks, log2 
 constexpr int kOffScratch = kOffRef + 2 * kRefPerParity;           // [QK wave 4]
 constexpr int kOffLm = kOffScratch + 4 * kScratchPerWave;          // [rt 2][W 2][3][32] f32: l, lq, m per row
 constexpr int kOffFlag = kOffLm + 2 * 2 * 3 * 32 * 4;              // 4 ints: redo votes of the PV waves
-constexpr int kLdsBytes = kOffFlag + 16;
+constexpr int kOffQr = kOffFlag + 16;                                 // [QK wave 4][4 k-steps][64 lanes] 16 B: Q rope fragments
+constexpr int kLdsBytes = kOffQr + 4 * 4096;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 constexpr int kStgStride = 128 + 4;                                // epilogue staging: floats per row (in the ring)
 static_assert(4 * 32 * kStgStride * 4 <= kRingSlots * kSlotBytes, "epilogue staging fits the ring");
@@ -98,7 +99,7 @@ __device__ __forceinline__ void scale_prep(float* __restrict__ scratch, float ks
 //      page's triples follow the P' store.  s_setprio 1 around the MFMA chain: the PV wave of this SIMD has its 8
 //      MFMAs ready at the same time, and they belong beside this wave's softmax, not inside its chain. ----
 __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w, const QkLane& lc, const int lane,
-                                        const v8i (&qn)[8], const v8bf (&qr)[4], const float qs, RopeRegs& rr,
+                                        const v8i (&qn)[8], const uint8_t* __restrict__ qr_lds, const float qs, RopeRegs& rr,
                                         const float ks_next, const uint8_t* __restrict__ rope_next,
                                         const float* __restrict__ scale_next, const uint8_t* __restrict__ kp,
                                         float* __restrict__ scratch, uint8_t* __restrict__ pbuf_w,
@@ -113,6 +114,11 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
   v16f acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // the Q rope fragments (16 registers) live in LDS between steps: with them and the second accumulator resident hipcc
+  // spilled a Q fragment (a scratch reload waits with vmcnt(0): the whole latency of the rope prefetch, every step)
+  v8bf qr[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qr[s] = as_bf8(*reinterpret_cast<const uint4*>(qr_lds + s * 1024 + lane * 16));
   uint4 ka[8][2];
   int kb0 = lc.kb0;   // opaque per step: the derived k-step offsets are not kept live across steps
   asm volatile("" : "+v"(kb0));
@@ -124,15 +130,40 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
     ka[s][0] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6)) + (s >> 2) * 256);
     ka[s][1] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6) ^ 16) + (s >> 2) * 256);
   }
+#ifndef FL_Y_DUAL_CHAIN
+#define FL_Y_DUAL_CHAIN 0
+#endif
+#if FL_Y_DUAL_CHAIN
+  // experiment (measured SLOWER: 136 vs 130 us; "operand reads + MFMA issue" 971 vs 771 cycles per step, drain 742 vs 625):
+  // two accumulate chains issued alternately, so that this wave always has a READY MFMA and its priority could keep the
+  // PV wave's MFMAs out of the chain.  The hypothesis behind it (a dependent MFMA loses the slot to the other wave's
+  // independent one every time) is therefore not what stretches the chain.
+  v16f acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(rr.ra[s]), qr[s], acc2, 0, 0, 0);
+    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(rr.ra[s]), qr[s], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (s & 1)
+      acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc2, 0, 0, 0, kUnitScale, 0, kUnitScale);
+    else
+      acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc, 0, 0, 0, kUnitScale, 0, kUnitScale);
+  }
+#else
 #pragma unroll
   for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(rr.ra[s]), qr[s], acc, 0, 0, 0);
 #pragma unroll
   for (int s = 0; s < 8; ++s)
     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc, 0, 0, 0, kUnitScale,
                                                           0, kUnitScale);
+#endif
   // operand reads: k-steps 0..3 before the rope MFMAs, k-step 4 + s behind the MFMA of k-step s (four k-steps = 32
   // registers in flight: with all eight hipcc runs out of registers beside Q and the two rope buffers)
-  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    // DS reads: k-steps 0..3
+  __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // DS reads: Q rope fragments, k-steps 0..3
   __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    // rope MFMAs
   // the scale triples of the lane's 16 tokens take over the operand registers of k-steps 0..3 behind the MFMAs of
   // k-steps 4..7, so that they have landed when the chain drains ({ks, log2 ks} now, 1/ks behind the scaling: 48
@@ -174,6 +205,14 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
   FL_T(8);   // rope / scale load issue
 
   // ---- online softmax of the block; tokens of lane: 32W + 8g + 4lh + e ----
+#if FL_Y_DUAL_CHAIN
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const float2v t = float2v{acc[r], acc[r + 1]} + float2v{acc2[r], acc2[r + 1]};
+    acc[r] = t[0];
+    acc[r + 1] = t[1];
+  }
+#endif
   float tmax = -INFINITY;
   if (!need_mask) {
     // PACKED f32 math (v_pk_mul_f32 / v_pk_fma_f32: two elements per instruction).  Beside a running MFMA a VALU
@@ -429,7 +468,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       // Q fragments (B operands), once per request
       const long long qrow = (long long)req * p.rows + row;
       v8i qn[8];
-      v8bf qr[4];
+      uint8_t* qr_lds = smem + kOffQr + w4 * 4096;
       float qs = 0.f;
       if (row_ok) {
         const uint8_t* qp = g_q_nope + qrow * kDN + lh * 32;
@@ -438,13 +477,14 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           qn[s] = make_v8i(*reinterpret_cast<const uint4*>(qp + s * 64), *reinterpret_cast<const uint4*>(qp + s * 64 + 16));
         const uint16_t* rp = g_q_rope + qrow * kDR + lh * 8;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qr[s] = as_bf8(*reinterpret_cast<const uint4*>(rp + s * 16));
+        for (int s = 0; s < 4; ++s)
+          *reinterpret_cast<uint4*>(qr_lds + s * 1024 + lane * 16) = *reinterpret_cast<const uint4*>(rp + s * 16);
         qs = g_q_scale[qrow] * p.scale_log2e;
       } else {
 #pragma unroll
         for (int s = 0; s < 8; ++s) qn[s] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qr[s] = as_bf8(make_uint4(0, 0, 0, 0));
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<uint4*>(qr_lds + s * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
       }
       int L_row = L;
       if (p.causal) L_row = L - (p.s_q - 1 - row / p.h_q);   // query j sees keys [0, L - (s_q-1-j))
@@ -486,7 +526,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           FL_T(0);   // barrier
           const int tok0w = (tile_b + i) * kPage + 32 * W;
           const bool need_mask = (tile_b + i) * kPage + kPage > L_min;
-          qk_step(l_run, lq_run, m_w, lc, lane, qn, qr, qs, rr, rn.ks, rope_next, scale_next,
+          qk_step(l_run, lq_run, m_w, lc, lane, qn, qr_lds, qs, rr, rn.ks, rope_next, scale_next,
                   smem + kOffRing + (i & 3) * kSlotBytes + W * (32 * kDN), scratch,
                   smem + kOffPbuf + (i & 1) * kPbufPerParity + (rt * 2 + W) * (64 * 16),
                   reinterpret_cast<float*>(smem + kOffRef + (i & 1) * kRefPerParity) + (rt * 2 + W) * 32, tok0w, L, L_row,

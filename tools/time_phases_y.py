@@ -16,7 +16,7 @@ meta, ns = fm.get_mla_metadata(wl["seqlens"], H, 1)
 qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
 pages = wl["pages"]
 nblocks = meta.shape[0] * ((H + 63) // 64)
-REC = 10
+REC = 14
 dbg = torch.zeros(nblocks * 8 * REC * 2, dtype=torch.int32, device=dev)
 lib.fl_mla_debug_set_buffer_y.argtypes = [ctypes.c_void_p]
 lib.fl_mla_debug_set_buffer_y(dbg.data_ptr())
@@ -28,11 +28,15 @@ torch.cuda.synchronize()
 d = dbg.cpu().numpy().view(np.uint64).reshape(nblocks, 8, REC).astype(np.float64)
 steps = (seq // 64) * bs / meta.shape[0]
 TICK = 10.0   # print unit: ticks x 10 (the counter runs at roughly the shader clock: read 'ns' as 0.1 ticks)
-for role, sl, names in (("QK waves", slice(0, 4), ["barrier wait", "softmax tail + publish", "loop control", "LDS drain", "B_n+normalisers+E0", "request prologue", "  operand reads + MFMA issue", "  MFMA drain+scale+max"]),
-                        ("PV waves", slice(4, 8), ["page-landed wait (vmcnt)", "barrier wait", "PV + refill issue + tail fill", "E0", "epilogue (store)", "request prologue", "-", "-"])):
+QK = ["barrier wait", "deferred sums + next scale prep (after publish)", "loop control", "LDS drain", "B_n + normalisers + E0", "request prologue",
+      "  K operand reads + MFMA issue", "  half-max exchange (permlane)", "  rope/scale load issue", "  MFMA drain + scaling + max", "  exp2 + e4m3 + publish", "  (mid barrier)"]
+PV = ["page-landed wait (vmcnt)", "barrier wait", "PV MFMAs + V^T reads + refill issue", "E0", "epilogue (store)", "request prologue", "  (to mid barrier)"] + ["-"] * 5
+for role, sl, names in (("QK waves", slice(0, 4), QK), ("PV waves", slice(4, 8), PV)):
     x = d[:, sl, :].reshape(-1, REC)
-    life = x[:, 8]
-    print(f"   shader clock while the waves ran: {(x[:, 8] / (x[:, 9] * 10.0)).mean():.2f} GHz (s_memtime cycles / wall_clock64 ns); wave wall time {x[:, 9].mean() / 100:.1f} us")
-    print(f"{role}: lifetime mean {life.mean()*TICK/1e3:.1f} us  min {life.min()*TICK/1e3:.1f}  max {life.max()*TICK/1e3:.1f}; {steps:.0f} steps per workgroup")
-    for i in range(8):
-        print(f"   {names[i]:32s} {x[:, i].mean()*TICK/steps:8.1f} ns/step  ({100*x[:, i].mean()/life.mean():5.1f} %)   total {x[:, i].mean()*TICK/1e3:7.2f} us")
+    x = x[x[:, 12] > 0]
+    life = x[:, 12]
+    ghz = (x[:, 12] / (x[:, 13] * 10.0)).mean()
+    print(f"{role}: lifetime mean {life.mean():.0f} cycles = {x[:, 13].mean() / 100:.1f} us wall (shader clock {ghz:.2f} GHz), min {life.min():.0f} max {life.max():.0f}; {steps:.0f} steps per workgroup")
+    for i in range(12):
+        if names[i] != "-":
+            print(f"   {names[i]:50s} {x[:, i].mean()/steps:8.1f} cycles/step  ({100*x[:, i].mean()/life.mean():5.1f} %)")
