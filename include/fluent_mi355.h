@@ -242,6 +242,25 @@ int fl_rope_inplace(const int64_t* positions, int64_t num_tokens, void* q, int64
                     int num_q_heads, void* k, int64_t k_stride_token, int64_t k_stride_head, int num_k_heads,
                     const float* cos_sin_cache, int64_t max_position, int rotary_dim, int is_neox, fl_stream_t stream);
 
+/* The same call with what models/deepseek_v2.py:843-861 (forward_absorb_prepare) passes on the decode path:
+ * output_q_rope / output_k_rope (rotated rows into a SEPARATE tensor, the source is left untouched; NULL = in place) and
+ * FusedSetKVBufferArg (models/utils.py:52-81, bf16 KV cache only — enable_fused_set_kv_buffer() is false for fp8 KV):
+ * v_buffer[cache_loc[t]] = value[t], k_buffer[cache_loc[t]] = rotated key[t] (k heads side by side), in the same launch.
+ * All strides in bf16 elements; cache_loc int64 or int32 [T], negative = skip the token. */
+typedef struct {
+  const int64_t* positions; int64_t num_tokens;
+  void* q; int64_t q_stride_token, q_stride_head; int num_q_heads;
+  void* k; int64_t k_stride_token, k_stride_head; int num_k_heads;
+  const float* cos_sin_cache; int64_t max_position; int rotary_dim; int is_neox;
+  void* q_out; int64_t qo_stride_token, qo_stride_head;
+  void* k_out; int64_t ko_stride_token, ko_stride_head;
+  void* k_buffer; int64_t k_buffer_stride;
+  void* v_buffer; int64_t v_buffer_stride;
+  const void* value; int64_t value_stride; int value_dim;
+  const void* cache_loc; int cache_loc_is_i64;
+} FlRopeArgs;
+int fl_rope(const FlRopeArgs* args, fl_stream_t stream);
+
 /* ---- K7: the work of copy_all_layer_kv_cache_tiled (srt/mem_cache/memory_pool.py:2055-2090) as
  * MLATokenToKVPool.move_kv_cache launches it (:746-777): for every buffer b of the table, rows tgt_loc[i] <- src_loc[i]
  * with the semantics of `buf[tgt] = buf[src]` (:756-763): all sources are read before any target is written (overlapping

@@ -8,8 +8,30 @@ two attention-wrapper classes FlashMLABackend's base class constructs (flashinfe
 north star)."""
 from fluent_mi355.gemm import sgl_per_token_group_quant_fp8, silu_and_mul  # noqa: F401
 from fluent_mi355.router import moe_fused_gate  # noqa: F401
-from fluent_mi355.rope import apply_rope_with_cos_sin_cache_inplace  # noqa: F401
+from fluent_mi355.rope import FusedSetKVBufferArg, apply_rope_with_cos_sin_cache_inplace  # noqa: F401
 
 from .attention_wrappers import BatchMLAPagedAttentionWrapper, BatchPrefillWithRaggedKVCacheWrapper  # noqa: F401
 
 from . import activation, comm, quantization  # noqa: F401
+
+import torch as _torch
+
+
+def dsv3_router_gemm(hidden_states, weight, out_dtype=_torch.float32):
+    """models/deepseek_v2.py:46,177-179 imports this name unconditionally and calls it only behind `is_sm90_supported()`;
+    on MI355X MoEGate.forward takes its `F.linear` branch.  Kept importable and correct: router logits
+    hidden [T, K] x weight [E, K]^T as ONE plain library GEMM (rocBLAS / hipBLASLt through torch), result in `out_dtype`."""
+    return _torch.nn.functional.linear(hidden_states, weight, None).to(out_dtype)
+
+
+def dsv3_fused_a_gemm(hidden_states, weight_t):
+    """models/deepseek_v2.py:46,785-793: the <= 16-token min-latency q_a/kv_a projection, behind
+    `use_min_latency_fused_a_gemm` (an sm90 switch).  Kept importable and correct as a plain library GEMM:
+    hidden [T, K] x weight_t [K, N]."""
+    return _torch.matmul(hidden_states, weight_t)
+
+
+def merge_state(v_a, s_a, v_b, s_b):
+    """models/deepseek_v2.py:43 imports this name for the chunked-PREFILL attention merge (out of the decode hot path,
+    SURVEY §8 'out of scope').  Importable; calling it is refused."""
+    raise RuntimeError("flashinfer.merge_state: prefill attention state merge is outside the MI355X hot-path build")

@@ -83,7 +83,28 @@ def test_get_mla_metadata_bit_exact(fm, lens, rows):
 
 
 # ---------------------------------------------------------------- K1: decode parity
+LAST_CASE = {}   # inputs of the most recent run_decode: a failing check() dumps them (a flake must leave evidence)
+
+
+def _dump_failure(tag, **arrays):
+    """inputs + outputs of a failed comparison -> gpurun_out/failures/<tag>.npz (merged back from the GPU box)"""
+    import os
+    import numpy as np
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "failures")
+    os.makedirs(root, exist_ok=True)
+    out = {}
+    for k, v in {**LAST_CASE, **arrays}.items():
+        if torch.is_tensor(v) and v.numel() * v.element_size() <= (64 << 20):
+            t = v.detach().cpu()
+            out[k] = (t.view(torch.int16) if t.dtype == torch.bfloat16 else t.view(torch.uint8) if t.dtype == torch.float8_e4m3fn else t).numpy()
+        elif isinstance(v, (int, float, bool, str)):
+            out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(root, "".join(ch if ch.isalnum() or ch in "-_" else "_" for ch in str(tag)) + ".npz"), **out)
+
+
 def run_decode(fm, c, H, s_q=1, causal=True, emulate=True):
+    LAST_CASE.clear()
+    LAST_CASE.update({k: v for k, v in c.items()}, H=H, s_q=s_q, causal=causal)
     d = {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in c.items()}
     pages = c["total_pages"]
     qn, qs, qr = fm.quantize_ckv_per_token_head(d["q"].contiguous(), 512)
@@ -110,6 +131,14 @@ MEASURED = []   # (tag, rel-MAE, max-abs, max|ref|, max LSE error): written out 
 
 
 def check(o, lse, ref, rlse, tag):
+    try:
+        return _check(o, lse, ref, rlse, tag)
+    except AssertionError:
+        _dump_failure(tag, o=o, lse=lse, ref=ref, rlse=rlse)
+        raise
+
+
+def _check(o, lse, ref, rlse, tag):
     assert torch.isfinite(o.float()).all(), tag
     err = (o.double() - ref).abs()
     rel = float(err.mean() / ref.abs().mean().clamp_min(1e-30))

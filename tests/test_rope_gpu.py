@@ -74,3 +74,44 @@ def test_rope_flat_layout_partial_rotary_and_bad_arguments():
         flashinfer.apply_rope_with_cos_sin_cache_inplace(pos.to(DEV), qd.float(), kd, D, cache.to(DEV))
     with pytest.raises(RuntimeError):
         flashinfer.apply_rope_with_cos_sin_cache_inplace(pos[:3].to(DEV), qd, kd, D, cache.to(DEV))
+
+
+@pytest.mark.parametrize("T,H,loc_dtype", [(1, 128, torch.int64), (128, 16, torch.int64), (37, 8, torch.int32)])
+def test_rope_absorb_prepare_call_output_q_rope_and_fused_set_kv(T, H, loc_dtype):
+    """The call forward_absorb_prepare makes (models/deepseek_v2.py:843-861): q_pe = q[..., 128:] rotated INTO the rope
+    columns of the absorbed Q [T, H, 576] (output_q_rope), k_pe rotated in place in K = latent[:, None, :], and — bf16 KV
+    cache — FusedSetKVBufferArg as models/utils.py:52-81 builds it from the MLA pool's [slots, 1, 576] buffer:
+    kv[loc, :512] = k_nope, kv[loc, 512:] = rotated k_pe.  Expected values: the in-place kernel (bit-exact vs the reference
+    golden above) + MLATokenToKVPool.set_kv_buffer's `buf[loc] = cat(k_nope, k_rope)`."""
+    import flashinfer
+
+    g = torch.Generator().manual_seed(T * 7 + H)
+    q = torch.randn(T, H, 192, generator=g).to(torch.bfloat16).to(DEV)
+    latent = torch.randn(T, 576, generator=g).to(torch.bfloat16).to(DEV)
+    cache = torch.randn(1000, 64, generator=g).to(DEV)
+    pos = torch.randint(0, 1000, (T,), generator=g).to(DEV)
+    slots = 4 * T + 5
+    loc = torch.randperm(slots, generator=g)[:T].to(loc_dtype).to(DEV)
+    # expected: in-place call on copies
+    q_ref, l_ref = q.clone(), latent.clone()
+    flashinfer.apply_rope_with_cos_sin_cache_inplace(pos, q_ref[..., 128:], l_ref[:, 512:].unsqueeze(1), 64, cache, is_neox=False)
+    kv_ref = torch.full((slots, 1, 576), 7.0, dtype=torch.bfloat16, device=DEV)
+    kv_ref[loc.long(), 0] = l_ref
+    # the decode-path call
+    Q = torch.full((T, H, 576), -3.0, dtype=torch.bfloat16, device=DEV)
+    K = latent.clone().unsqueeze(1)
+    kv = torch.full((slots, 1, 576), 7.0, dtype=torch.bfloat16, device=DEV)
+    q_in = q.clone()
+    arg = flashinfer.FusedSetKVBufferArg(value=K[..., :512], k_buffer=kv[..., 512:].view(slots, -1), v_buffer=kv[..., :512].view(slots, -1),
+                                         k_scale=None, v_scale=None, cache_loc=loc)
+    flashinfer.apply_rope_with_cos_sin_cache_inplace(pos, q_in[..., 128:], K[..., 512:], 64, cache, is_neox=False,
+                                                     fused_set_kv_buffer_arg=arg, output_q_rope=Q[..., 512:])
+    torch.cuda.synchronize()
+    assert torch.equal(Q[..., 512:], q_ref[..., 128:]) and bool((Q[..., :512] == -3.0).all())
+    assert torch.equal(q_in, q)                                   # the source of a separate output is left untouched
+    assert torch.equal(K[:, 0], l_ref)                            # k_pe rotated in place, k_nope untouched
+    assert torch.equal(kv, kv_ref)                                # cache rows written, every other row untouched
+    with pytest.raises(RuntimeError, match="bf16 cache"):
+        arg.k_scale = 0.5
+        flashinfer.apply_rope_with_cos_sin_cache_inplace(pos, q_in[..., 128:], K[..., 512:], 64, cache, is_neox=False,
+                                                         fused_set_kv_buffer_arg=arg)
