@@ -37,9 +37,12 @@ int fl_mla_x_rows_per_wg() {
   // query rows one workgroup of mla_decode_fp8_x.hip owns when a request has more than 64: 128 (one workgroup streams a
   // KV part once for all rows; long requests are split along KV) or, with FLUENT_MLA_X_ROWS=64, 64 (row groups of one
   // request run as neighbouring workgroups of one XCD and share the KV stream through its L2; fewer KV splits)
+  // With the role-specialised mapping on (fl_mla_use_y) the scheduler counts parts for 64-row workgroups whatever the KV
+  // format (get_mla_metadata does not know it): the plain-fp8 format then runs this file's 64-row form too, so that
+  // num_parts x row groups still fills the chip.
   static const int rows = [] {
     const char* e = getenv("FLUENT_MLA_X_ROWS");
-    return (e != nullptr && atoi(e) == 64) ? 64 : 128;
+    return (fl_mla_use_y() || (e != nullptr && atoi(e) == 64)) ? 64 : 128;
   }();
   return rows;
 }
