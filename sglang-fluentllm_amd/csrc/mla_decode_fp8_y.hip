@@ -33,7 +33,7 @@ constexpr int kPbufPerParity = 2 * 2 * 64 * 16;                    // [rt 2][W 2
 constexpr int kOffPbuf = kOffRing + kRingSlots * kSlotBytes;       // [parity 2]
 constexpr int kRefPerParity = 2 * 2 * 32 * 4;                      // [rt 2][W 2][32 rows] f32
 constexpr int kOffRef = kOffPbuf + 2 * kPbufPerParity;             // [parity 2]
-constexpr int kScratchPerWave = 3 * 32 * 4;                        // {ks, log2 ks, 1/ks} x 32 tokens
+constexpr int kScratchPerWave = 2 * 3 * 32 * 4;                    // [page parity 2] {ks, log2 ks, 1/ks} x 32 tokens
 constexpr int kOffScratch = kOffRef + 2 * kRefPerParity;           // [QK wave 4]
 constexpr int kOffLm = kOffScratch + 4 * kScratchPerWave;          // [rt 2][W 2][3][32] f32: l, lq, m per row
 constexpr int kOffFlag = kOffLm + 2 * 2 * 3 * 32 * 4;              // 4 ints: redo votes of the PV waves
@@ -102,7 +102,8 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
                                         const v8i (&qn)[8], const uint8_t* __restrict__ qr_lds, const float qs, RopeRegs& rr,
                                         const float ks_next, const uint8_t* __restrict__ rope_next,
                                         const float* __restrict__ scale_next, const uint8_t* __restrict__ kp,
-                                        float* __restrict__ scratch, uint8_t* __restrict__ pbuf_w,
+                                        float* __restrict__ scratch, float* __restrict__ scratch_next,
+                                        uint8_t* __restrict__ pbuf_w,
                                         float* __restrict__ ref_w, const int tok0w, const int L, const int L_row,
                                         const bool need_mask FL_T_PARAMS) {
   const int li = lane & 31, lh = lane >> 5;
@@ -178,10 +179,33 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
 #ifndef FL_Y_TRIPLES_IN_CHAIN
 #define FL_Y_TRIPLES_IN_CHAIN 1
 #endif
+#ifndef FL_Y_TAIL_IN_CHAIN
+#define FL_Y_TAIL_IN_CHAIN 0   // experiment (measured: no gain, 133-135 vs 130-135 us): the rope / scale loads of page i+2 and
+                               // the scale triples of page i+1 issued INSIDE this step's MFMA chain instead of behind it.  The
+                               // phase timer shows why: the chain phase grows by exactly what the tail shrinks (771 -> 1083
+                               // cycles; tail 217 -> 81, rope loads 119 -> 4) — the chain's issue slots are not free
+#endif
+#ifndef FL_Y_TAIL_GROUPS
+#define FL_Y_TAIL_GROUPS 0
+#endif
+#if FL_Y_TAIL_IN_CHAIN
+  // rope A operand / raw scale of page i+2 into the registers the rope MFMAs have read (UNCONDITIONAL, see below)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) rr.ra[s] = *reinterpret_cast<const uint4*>(rope_next + s * 32);
+  rr.ks = *scale_next;
+  scale_prep(scratch_next, ks_next, tok0w + kPage, li, L);
+#endif
 #pragma unroll
   for (int s = 0; s < (FL_Y_TRIPLES_IN_CHAIN ? 8 : 4); ++s) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#if FL_Y_TAIL_IN_CHAIN
+#if FL_Y_TAIL_GROUPS == 1
+    if (s == 1) __builtin_amdgcn_sched_group_barrier(0x020, 5, 0);   // VMEM reads: rope + scale of page i+2
+#elif FL_Y_TAIL_GROUPS == 2
+    if (s == 7) __builtin_amdgcn_sched_group_barrier(0x020, 5, 0);
+#endif
+#endif
   }
   if (!FL_Y_TRIPLES_IN_CHAIN) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
   __builtin_amdgcn_sched_barrier(0);
@@ -198,10 +222,12 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
   // rope A operand / raw scale of page i+2 into the registers the rope MFMAs have read: token 32W + li, 16-B chunks
   // 2s + lh of its 128-B row.  UNCONDITIONAL (the caller clamps the page into the part): behind a conditional load hipcc
   // can only wait with vmcnt(0), which would expose the whole latency of the loads issued one step earlier, every step
+#if !FL_Y_TAIL_IN_CHAIN
 #pragma unroll
   for (int s = 0; s < 4; ++s) rr.ra[s] = *reinterpret_cast<const uint4*>(rope_next + s * 32);
   rr.ks = *scale_next;
   __builtin_amdgcn_sched_barrier(0);
+#endif
   FL_T(8);   // rope / scale load issue
 
   // ---- online softmax of the block; tokens of lane: 32W + 8g + 4lh + e ----
@@ -296,7 +322,9 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
     l_run = l2[0] + l2[1];
     lq_run = q2[0] + q2[1];
   }
-  scale_prep(scratch, ks_next, tok0w + kPage, li, L);
+#if !FL_Y_TAIL_IN_CHAIN
+  scale_prep(scratch_next, ks_next, tok0w + kPage, li, L);
+#endif
 }
 
 // ---- PV wave: O^T[256 dims x 32 rows] += V^T(page) . P^T, with the LDS-DMA refill of a later page in the MFMA shadow ----
@@ -509,7 +537,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
         if (pass == 1) load_window(0);
         load_rope(rA, 0);
         load_rope(rB, n > 1 ? 1 : 0);
-        scale_prep(scratch, rA.ks, tile_b * kPage + 32 * W, li, L);   // (this wave's reads of the previous request are done)
+        scale_prep(scratch, rA.ks, tile_b * kPage + 32 * W, li, L);   // page 0 -> parity 0 (this wave's reads of the previous request are done)
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // R0: every wave is done with the LDS of the previous request / pass
@@ -527,7 +555,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           const int tok0w = (tile_b + i) * kPage + 32 * W;
           const bool need_mask = (tile_b + i) * kPage + kPage > L_min;
           qk_step(l_run, lq_run, m_w, lc, lane, qn, qr_lds, qs, rr, rn.ks, rope_next, scale_next,
-                  smem + kOffRing + (i & 3) * kSlotBytes + W * (32 * kDN), scratch,
+                  smem + kOffRing + (i & 3) * kSlotBytes + W * (32 * kDN), scratch + (i & 1) * 96, scratch + ((i + 1) & 1) * 96,
                   smem + kOffPbuf + (i & 1) * kPbufPerParity + (rt * 2 + W) * (64 * 16),
                   reinterpret_cast<float*>(smem + kOffRef + (i & 1) * kRefPerParity) + (rt * 2 + W) * 32, tok0w, L, L_row,
                   need_mask FL_T_ARGS);
