@@ -92,6 +92,10 @@ typedef struct FlMlaDecodeArgs {
 } FlMlaDecodeArgs;
 
 int fl_mla_decode(const FlMlaDecodeArgs* args, fl_stream_t stream);
+/* Sizes of the two workspaces above for a launch of this shape (the partial rows are bf16 or f32 depending on the
+ * mapping the shape dispatches to; allocate exactly this much, e.g. from the graph's memory pool). */
+int fl_mla_workspace_bytes(int kv_format, int bs, int s_q, int h_q, int num_parts, int64_t* o_accum_bytes,
+                           int64_t* lse_accum_bytes);
 
 /* ---- G1-G4: deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_{offset,contiguous,masked} / gemm_fp8_fp8_bf16_nt
  * (srt/layers/moe/gemms/fp8/fire.py:18 -> moe/executors/fp8_eps_executor.py:56,78;

@@ -872,6 +872,24 @@ int fl_mla_launch_combine(const Params& p, const int32_t* num_splits, hipStream_
 int fl_mla_decode_fp8_x_impl(const FlMlaDecodeArgs* a, const Params& p, hipStream_t stream);   // mla_decode_fp8_x.hip
 int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p, hipStream_t stream);   // mla_decode_fp8_y.hip
 
+// bytes of the split-partials workspaces fl_mla_decode needs for a launch of this shape — the SAME dispatch rule as below
+// decides whether partials are bf16 rows (role-specialised / slot-pipelined mappings) or f32 rows
+extern "C" int fl_mla_workspace_bytes(int kv_format, int bs, int s_q, int h_q, int num_parts, int64_t* o_accum_bytes,
+                                      int64_t* lse_accum_bytes) {
+  FL_CHECK_ARG(o_accum_bytes && lse_accum_bytes && bs >= 0 && s_q >= 1 && h_q >= 1 && num_parts >= 1, "fl_mla_workspace_bytes: bad arguments");
+  const long long rows = (long long)s_q * h_q;
+  static const bool x_small = [] {
+    const char* e = getenv("FLUENT_MLA_X_SMALL");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  bool bf16_partials = false;
+  if (kv_format == FL_KV_FP8_PER_TOKEN && fl_mla_use_y() && rows > 32) bf16_partials = true;
+  else if (kv_format != FL_KV_BF16_576 && fl_mla_use_x() && (rows > 64 || (x_small && rows > 32))) bf16_partials = true;
+  *o_accum_bytes = (long long)(bs + num_parts) * rows * 512 * (bf16_partials ? 2 : 4);
+  *lse_accum_bytes = (long long)(bs + num_parts) * rows * 2 * 4;
+  return FL_OK;
+}
+
 int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   const bool per_token = a->kv_format == FL_KV_FP8_PER_TOKEN;
   FL_CHECK_ARG(a->d_nope == kDN && a->d_rope == kDR, "fl_mla_decode: only d_nope=512,d_rope=64 (got %d,%d)",

@@ -102,6 +102,11 @@ def dequantize_ckv_fused_indexed(k_lora_fp8: torch.Tensor, k_rope: torch.Tensor,
     return lora, rope
 
 
+lib.fl_mla_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+lib.fl_mla_workspace_bytes.restype = ctypes.c_int
+
+
 def _decode(args: FlMlaDecodeArgs, dev):
     check(lib.fl_mla_decode(ctypes.byref(args), stream_ptr(dev)), "fl_mla_decode")
 
@@ -130,8 +135,11 @@ def _common(args, q_like, block_table, cache_seqlens, tile_scheduler_metadata, n
     args.num_splits = num_splits.data_ptr()
     out = torch.empty((bs, s_q, h_q, 512), dtype=torch.bfloat16, device=dev)
     lse = torch.empty((bs, h_q, s_q), dtype=torch.float32, device=dev)
-    o_accum = torch.empty((bs + num_parts, rows, 512), dtype=torch.float32, device=dev)
-    lse_accum = torch.empty((bs + num_parts, rows, 2), dtype=torch.float32, device=dev)
+    ob, lb = ctypes.c_int64(), ctypes.c_int64()
+    check(lib.fl_mla_workspace_bytes(int(args.kv_format), bs, s_q, h_q, num_parts, ctypes.byref(ob), ctypes.byref(lb)),
+          "fl_mla_workspace_bytes")
+    o_accum = torch.empty((ob.value,), dtype=torch.uint8, device=dev)       # bf16 or f32 partial rows: the library says which
+    lse_accum = torch.empty((lb.value,), dtype=torch.uint8, device=dev)
     args.out, args.lse, args.o_accum, args.lse_accum = out.data_ptr(), lse.data_ptr(), o_accum.data_ptr(), lse_accum.data_ptr()
     return out, lse, (o_accum, lse_accum)
 

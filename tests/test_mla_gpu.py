@@ -253,7 +253,7 @@ def test_decode_vs_reference_backend_golden(fm):
         assert float((o.cpu().float() - ref.float()).abs().max()) < 2e-1, name
 
 
-def _full_size_properties(fm, lens, H, samples, tag):
+def _full_size_properties(fm, lens, H, samples, tag, s_q=1):
     """Full-size checks where the oracle is too slow for the whole batch — size-independent properties:
     (1) o is a convex combination of V rows: |o| <= max|V|; (2) moving every page to another physical location (same
     logical content) leaves the output BIT-identical; (3) a sampled subset of requests matches the oracle."""
@@ -275,9 +275,9 @@ def _full_size_properties(fm, lens, H, samples, tag):
         o0 += n
     bt = bt.to(dev())
     seq = torch.tensor(lens, dtype=torch.int32, device=dev())
-    q = torch.randn(bs, 1, H, 576, device=dev(), generator=g, dtype=torch.float32).to(torch.bfloat16)
+    q = torch.randn(bs, s_q, H, 576, device=dev(), generator=g, dtype=torch.float32).to(torch.bfloat16)
     qn, qs, qr = fm.quantize_ckv_per_token_head(q, 512)
-    meta, ns = fm.get_mla_metadata(seq, H, 1)
+    meta, ns = fm.get_mla_metadata(seq, s_q * H, 1)
 
     def run(kl, ks, kr, table):
         return fm.flash_mla_ckv_fp8_per_token(qn, qr, kl.view(pages, 64, 1, 512), kr.view(pages, 64, 1, 64), qs,
@@ -303,6 +303,12 @@ def _full_size_properties(fm, lens, H, samples, tag):
         ref, rlse = mla_ref.mla_decode_fp8_per_token(qn[b:b + 1].cpu(), qs[b:b + 1].cpu(), qr[b:b + 1].cpu(), kl_c, ks_c, kr_c,
                                                      bt[b:b + 1].cpu(), seq[b:b + 1].cpu(), SCALE, True)
         check(o[b:b + 1].cpu(), lse[b:b + 1].cpu(), ref, rlse, f"{tag} req {b} (len {lens[b]})")
+
+
+def test_full_size_properties_cfg5_mtp_verify(fm):
+    """BASELINE config 5 at full size: MTP verify, s_q=4 (causal over the 4 draft tokens), bs=64, seq=16384, H=64 — 256 query
+    rows per request; cache_seqlens include the s_q new tokens (flashmla_backend.py:135-136)."""
+    _full_size_properties(fm, [16384] * 64, 64, (0, 63), "cfg5", s_q=4)
 
 
 def test_full_size_properties_bs128_seq4096(fm):
