@@ -5,8 +5,12 @@
  * (citations are /root/reference/python/sglang/... file:line of the call site replaced).
  * Conventions: plain pointers to DEVICE memory unless the name says host; sizes in elements;
  * `stream` is a hipStream_t passed as void*; return 0 = ok, non-zero = error (message via
- * fl_last_error()).  No entry point synchronises the host, allocates device memory, or keeps
- * global mutable state: everything is hipGraph-capturable (srt/model_executor/cuda_graph_runner.py:433).
+ * fl_last_error()).  Compute entry points neither synchronise the host nor allocate device memory: they
+ * are hipGraph-capturable (srt/model_executor/cuda_graph_runner.py:433).  Exceptions, all named: the
+ * one-shot communicator's setup / teardown / fl_comm_check (fl_comm_create .. fl_comm_destroy allocate,
+ * map and synchronise — called outside the captured region), and the ONE piece of process-global
+ * state, fl_gemm_set_num_cus (deep_gemm.set_num_sms is process-global in the reference as well);
+ * besides that only a thread-local error string and a cached CU count are kept.
  */
 #ifndef FLUENT_MI355_H
 #define FLUENT_MI355_H

@@ -145,8 +145,8 @@ def _check(o, lse, ref, rlse, tag):
     _fin = torch.isfinite(rlse)
     MEASURED.append({"case": str(tag), "rel_mae": rel, "max_abs": float(err.max()), "max_ref": float(ref.abs().max()),
                      "lse_err": float((lse.double()[_fin] - rlse[_fin]).abs().max()) if bool(_fin.any()) else 0.0})
-    # stated FP8 tolerance vs dequantise-then-exact attention: rel-MAE < 2.7e-2 = 1.25 x the worst MEASURED case (2.15e-2 over
-    # the 30 cases of this file incl. the full-size ones: profiles/r02_mla_parity_measured.json), max-abs < 1e-1 on
+    # stated FP8 tolerance vs dequantise-then-exact attention: rel-MAE < 2.7e-2 = 1.16 x the worst MEASURED case (2.33e-2, h40_padrows,
+    # over the 32 cases of this file incl. the full-size ones: profiles/r02_mla_parity_measured.json; 1.25 x was the plan at 2.15e-2), max-abs < 1e-1 on
     # N(0,1)-scaled data (|o| <= ~4; for larger outputs the absolute bound scales with the data).  SURVEY section 8c's 2e-2
     # is what exact P would give; here P is re-quantised to e4m3 for the MX PV MFMA (3 mantissa bits, rms relative rounding
     # 2^-4/sqrt(3) = 3.6 % per weight): on i.i.d. V rows signal and rounding noise both scale as 1/sqrt(N_eff), so rel-MAE
