@@ -72,6 +72,70 @@ def layer_call(fm, wl, l, meta, ns):
                                           SCALE, True)
 
 
+def k1_ragged_variant(dev, layers=8):
+    """SURVEY section 8(d) variant of the headline workload: cfg2 with RAGGED lengths uniform in 2048..6144 (mean 4096): K1 only,
+    `layers` layer caches captured in one hipGraph, HIP events on the launch stream -> us per launch + achieved algorithmic GB/s."""
+    import flash_mla_fp8 as fm
+
+    g = torch.Generator(device=dev).manual_seed(77)
+    lens = torch.randint(2048, 6145, (BS,), device=dev, generator=g, dtype=torch.int32)
+    npg = ((lens + 63) // 64).tolist()
+    mp, pages = max(npg), sum(npg) + 1
+    slots = pages * 64
+    key = torch.randn(slots, 1, 576, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    caches = []
+    for l in range(layers):
+        k_lora = torch.empty(slots, 1, 512, dtype=torch.uint8, device=dev)
+        k_scale = torch.empty(slots, 1, 1, dtype=torch.float32, device=dev)
+        k_rope = torch.empty(slots, 1, 64, dtype=torch.bfloat16, device=dev)
+        idx = ((torch.arange(slots, device=dev, dtype=torch.int64) + 64 * 7 * l) % slots).to(torch.int32)
+        fm.quantize_and_cache_k(key, k_lora, k_scale, k_rope, idx, 512)
+        caches.append((k_lora, k_scale, k_rope))
+    del key
+    perm = (torch.randperm(pages - 1, device=dev, generator=g).to(torch.int32) + 1).cpu()
+    bt = torch.zeros(BS, mp, dtype=torch.int32)
+    o = 0
+    for b, n in enumerate(npg):
+        bt[b, :n] = perm[o:o + n]
+        o += n
+    bt = bt.to(dev)
+    q = torch.randn(BS, S_Q, H, 576, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    qn, qs, qr = fm.quantize_ckv_per_token_head(q, 512)
+    meta, ns = fm.get_mla_metadata(lens, S_Q * H, 1)
+
+    def k1(l):
+        k_lora, k_scale, k_rope = caches[l]
+        fm.flash_mla_ckv_fp8_per_token(qn, qr, k_lora.view(pages, 64, 1, 512), k_rope.view(pages, 64, 1, 64), qs,
+                                       k_scale.view(pages, 64, 1, 1), bt, lens, 512, meta, ns, SCALE, True)
+
+    for l in range(layers):
+        k1(l)
+    torch.cuda.synchronize()
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s2):
+        k1(0)
+    torch.cuda.current_stream().wait_stream(s2)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for l in range(layers):
+            k1(l)
+    gr.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        gr.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / (reps * layers)
+    alg = int(sum(int(L) * 644 + S_Q * H * 644 + S_Q * H * 1024 + 4 * ((int(L) + 63) // 64) for L in lens.tolist()))
+    return {"workload": "cfg2 ragged: bs=128, lengths uniform in 2048..6144, H=128, K1 only", "us_per_launch": round(t * 1e6, 2),
+            "GBs": round(alg / t / 1e9, 1), "hbm_frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg,
+            "splits": int(ns[-1]) - BS}
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -219,6 +283,27 @@ def gemm_roofline(dev):
             res["T16384_random_bytes"] = {"ms": round(t2 * 1e3, 3), "TFLOPs": round(flops / t2 / 1e12, 1),
                                           "mfma_frac": round(flops / t2 / 1e12 / 5000.0, 4)}
             del xq2
+        del xq, xs
+    # SURVEY section 8(d) variants of the compute regime (operands: the random bytes left in `w`, N(0,1)/10 activations):
+    # Zipf-skewed routing at T=16384 (expert e drawn with weight 1/(e+1): a few experts take thousands of rows, a long tail
+    # gets none) and T=32768 with uniform routing
+    for name, T, zipf in (("T16384_zipf", 16384, True), ("T32768", 32768, False)):
+        M = T * TOPK
+        if zipf:
+            wgt = 1.0 / torch.arange(1, E + 1, device=dev, dtype=torch.float32)
+            ids = torch.multinomial(wgt.expand(2048, E), TOPK, replacement=False, generator=g)
+        else:
+            ids = torch.stack([torch.randperm(E, device=dev, generator=g)[:TOPK] for _ in range(2048)])
+        ids = ids.repeat((T + 2047) // 2048, 1)[:T].reshape(-1)
+        counts = torch.bincount(ids, minlength=E)
+        ex = torch.zeros(E + 1, dtype=torch.int32, device=dev)
+        ex[1:] = torch.cumsum(counts, 0)
+        xq = (torch.randn(M, HID, device=dev, generator=g) / 10).to(torch.float8_e4m3fn)
+        xs = torch.rand(M, HID // 128, device=dev, generator=g) * 1e-2 + 1e-3
+        t = timed(T, 3, xq, xs, ex, M)
+        flops = 2.0 * M * N * HID
+        res[name] = {"ms": round(t * 1e3, 3), "TFLOPs": round(flops / t / 1e12, 1), "mfma_frac": round(flops / t / 1e12 / 5000.0, 4),
+                     "experts_hit": int((counts > 0).sum()), "max_rows_per_expert": int(counts.max())}
         del xq, xs
     res["mfma_frac"] = res["T16384"]["mfma_frac"]          # of the 5 PFLOP/s dense fp8 peak
     res["T128_hbm_frac"] = res["T128"]["hbm_frac"]         # weight stream, of 8 TB/s
@@ -371,8 +456,11 @@ def main():
                 "algorithmic_bytes_per_launch": alg}
     cpu = None
     gemm = None
+    variants = None
     if rank == 0 and world == 1 and not a.no_gemm:
         del wl
+        torch.cuda.empty_cache()
+        variants = {"cfg2_ragged": k1_ragged_variant(dev)}
         torch.cuda.empty_cache()
         gemm = gemm_roofline(dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -387,7 +475,7 @@ def main():
                                    "pages randomly permuted, K3 metadata once + 61 layers x (K5 store + K4 quant-q + K1 decode) per step",
                        "bs_per_gpu": BS, "seq_len": SEQ, "heads": H, "layers_per_step": layers,
                        "parallelism": f"dp{world} (DP-attention, no data-path collective)", "hipgraph": graph is not None},
-            "roofline": roof, "gemm": gemm, "cpu_baseline": cpu}))
+            "roofline": roof, "gemm": gemm, "variants": variants, "cpu_baseline": cpu}))
     if dist is not None:
         dist.destroy_process_group()
 
