@@ -451,7 +451,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": ("mla_decode_y_kernel" if (y_on and H * S_Q > 32) else
                            "mla_decode_x_kernel" if (H * S_Q > 64 and os.environ.get("FLUENT_MLA_X") != "0")
-                           else "mla_decode_fp8_kernel") + " (+ mla_combine_kernel: early exit, nothing is split at this shape)",
+                           else "mla_decode_fp8_kernel") + (" (no merge kernel: split requests are merged inside the decode kernel; none is split at this shape)"
+                                                            if (y_on and H * S_Q > 32) else " (+ mla_combine_kernel)"),
                 "us_per_launch": round(per_launch_s * 1e6, 2),
                 "algorithmic_bytes_per_launch": alg}
     cpu = None

@@ -85,7 +85,8 @@ typedef struct FlMlaDecodeArgs {
   const int32_t* block_table; /* i32 [bs, block_table_stride] page ids (bit-exact, allocator.py:60-102) */
   int64_t block_table_stride;
   const int32_t* cache_seqlens; /* i32 [bs] */
-  const int32_t* tile_scheduler_metadata; /* from fl_mla_get_metadata */
+  const int32_t* tile_scheduler_metadata; /* from fl_mla_get_metadata; columns 5..7 of every row are scratch counters of the
+                                            * in-kernel split merge: zero on entry, zero again when the launch has finished */
   const int32_t* num_splits;
   /* outputs */
   void* out;                /* bf16 [bs,s_q,h_q,d_nope] */

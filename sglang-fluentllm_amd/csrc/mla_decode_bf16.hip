@@ -296,6 +296,7 @@ int fl_mla_decode_bf16_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   p.num_pages = a->num_pages; p.bt_stride = a->block_table_stride;
   p.out = (uint16_t*)a->out; p.lse = a->lse; p.o_accum = a->o_accum; p.lse_accum = a->lse_accum;
   p.partial_bf16 = 0;
+  p.merge_in_kernel = 0;
   p.row_groups = (p.rows + 31) / 32;
   const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(256);
   mla_decode_bf16_kernel<<<grid, block, 0, stream>>>(p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata,

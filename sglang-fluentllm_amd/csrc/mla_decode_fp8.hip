@@ -910,6 +910,7 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   p.num_pages = a->num_pages; p.bt_stride = a->block_table_stride;
   p.out = (uint16_t*)a->out; p.lse = a->lse; p.o_accum = a->o_accum; p.lse_accum = a->lse_accum;
   p.partial_bf16 = 0;
+  p.merge_in_kernel = 0;
   // The slot-pipelined mapping (mla_decode_fp8_x.hip): 128-row workgroups for rows > 64 (e.g. TP1, H=128); for 33..64 rows
   // two compute waves + two loader waves (measured H=64: 102.5 vs 114 us; FLUENT_MLA_X_SMALL=0 keeps this file's kernel).
   // At most 32 rows stay here: ONE slot-pipelined compute wave would carry all 40 MFMAs of a page on one SIMD (H=16:

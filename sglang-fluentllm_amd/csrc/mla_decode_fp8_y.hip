@@ -38,7 +38,8 @@ constexpr int kOffScratch = kOffRef + 2 * kRefPerParity;           // [QK wave 4
 constexpr int kOffLm = kOffScratch + 4 * kScratchPerWave;          // [rt 2][W 2][3][32] f32: l, lq, m per row
 constexpr int kOffFlag = kOffLm + 2 * 2 * 3 * 32 * 4;              // 4 ints: redo votes of the PV waves
 constexpr int kOffQr = kOffFlag + 16;                                 // [QK wave 4][4 k-steps][64 lanes] 16 B: Q rope fragments
-constexpr int kLdsBytes = kOffQr + 4 * 4096;
+constexpr int kOffMerge = kOffQr + 4 * 4096;                            // 2 ints: PV-wave arrivals, merge verdict (in-kernel split merge)
+constexpr int kLdsBytes = kOffMerge + 16;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 constexpr int kStgStride = 128 + 4;                                // epilogue staging: floats per row (in the ring)
 static_assert(4 * 32 * kStgStride * 4 <= kRingSlots * kSlotBytes, "epilogue staging fits the ring");
@@ -425,7 +426,7 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, con
 
 __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const Params p, const int32_t* __restrict__ g_block_table, const int32_t* __restrict__ g_seqlens,
-    const int32_t* __restrict__ g_meta, const int32_t* __restrict__ g_num_splits,
+    const int32_t* __restrict__ g_meta, int32_t* g_merge_ctr, const int32_t* __restrict__ g_num_splits,
     const uint8_t* __restrict__ g_k_nope, const uint16_t* __restrict__ g_k_rope, const float* __restrict__ g_k_scale,
     const uint8_t* __restrict__ g_q_nope, const uint16_t* __restrict__ g_q_rope, const float* __restrict__ g_q_scale) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[kLdsBytes];
@@ -638,6 +639,9 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     lc.dn_row = (unsigned)((w4 * kPiecesPerWave * 2 + lh) * kDN);
     lc.dn_x = (unsigned)((li ^ lh) << 4);
   }
+  int* msync = reinterpret_cast<int*>(smem + kOffMerge);
+  if (wave_id == 4 && lane == 0) { msync[0] = 0; msync[1] = 0; }   // (first read behind the first request's barriers)
+  int frag_seq = 1;   // split fragments this workgroup has finished + 1 (identical in its four PV waves)
   for (; req < p.bs; ++req, tile_b = 0, split_idx = 0) {
     FL_Y_REQUEST_HEAD();
     const int split_base = g_num_splits[req];
@@ -737,9 +741,9 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const float lseq_nat = lq > 0.f ? (__builtin_amdgcn_logf(lq) + m_o - kPShift) * 0.6931471805599453f : -INFINITY;
     const int slot_idx = split_base + split_idx;
     if (row_ok && lh == 0 && W == 0) {
-      if (is_split) {
-        p.lse_accum[((long long)slot_idx * p.rows + row) * 2 + 0] = lseq_nat;
-        p.lse_accum[((long long)slot_idx * p.rows + row) * 2 + 1] = lse_nat;
+      if (is_split) {   // (agent-scope stores: read by whichever part merges the request, see the merge below)
+        st_agent_f32(p.lse_accum + ((long long)slot_idx * p.rows + row) * 2 + 0, lseq_nat);
+        st_agent_f32(p.lse_accum + ((long long)slot_idx * p.rows + row) * 2 + 1, lse_nat);
       } else {
         const int j = row / p.h_q, h = row - j * p.h_q;
         p.lse[((long long)req * p.h_q + h) * p.s_q + j] = lse_nat;
@@ -776,7 +780,55 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           ov.y = fl_pack_bf16(v0.z, v0.w);
           ov.z = fl_pack_bf16(v1.x, v1.y);
           ov.w = fl_pack_bf16(v1.z, v1.w);
-          if (row0 + r < p.rows) *reinterpret_cast<uint4*>(dbase + (long long)r * kDN) = ov;
+          if (row0 + r < p.rows) {
+            if (is_split) st_agent_16B(dbase + (long long)r * kDN, ov);
+            else *reinterpret_cast<uint4*>(dbase + (long long)r * kDN) = ov;
+          }
+        }
+      }
+    }
+    // ---- split-KV merge WITHOUT a second kernel: the part that finishes a (request, row group) LAST merges it.  Every PV
+    //      wave waits for its partial stores, the fourth one of the workgroup bumps the (request, row group) counter in the
+    //      spare metadata columns of the request's first part (16 bits per row group; K3 zeroes them, the merging part
+    //      puts them back to zero: the same metadata serves every layer's launch), and tells its three siblings through
+    //      LDS whether this workgroup is the last.  The last one reads the other parts' partials (agent-scope loads of
+    //      agent-scope stores: no cache-wide fence) and writes the final rows, 16 rows per PV wave (combine_rows16). ----
+    if (is_split && p.merge_in_kernel) {
+      // this wave's partial stores are pushed past the XCD's L2 before anything downstream can count the fragment as done:
+      // a RELEASE fence at agent scope (L2 write-back + wait; it invalidates nothing, the page streams of the other
+      // workgroups keep their lines).  A bare s_waitcnt vmcnt(0) was not enough: the bit-identity test of the ragged
+      // full-size case caught a merge that had read a partial row before it left the writer's L2.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef FL_Y_MERGE_RELEASE_FENCE
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+      int verdict = 0;
+      if (lane == 0) {
+        const int old = __hip_atomic_fetch_add(msync, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((old & 3) == 3) {
+          const int nsplit = g_num_splits[req + 1] - split_base;
+          int* ctr = g_merge_ctr + (long long)(part - split_idx) * FL_MLA_META_W + 5 + (rgrp >> 1);
+          const int sh = 16 * (rgrp & 1);
+          const int g_old = (atomicAdd(ctr, 1 << sh) >> sh) & 0xffff;
+          int st = 1;
+          if (g_old == nsplit - 1) {
+            st = 2;
+            atomicSub(ctr, nsplit << sh);
+          }
+          __hip_atomic_store(msync + 1, (frag_seq << 2) | st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        while (((verdict = __hip_atomic_load(msync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 2) != frag_seq)
+          __builtin_amdgcn_s_sleep(1);
+      }
+      verdict = __builtin_amdgcn_readfirstlane(verdict);
+      ++frag_seq;
+      if ((verdict & 3) == 2) {
+        const int nsplit = g_num_splits[req + 1] - split_base;
+        const int rb = rgrp * 64 + w4 * 16;
+        if (rb < p.rows) {
+          if (nsplit == 2) combine_rows16<2>(p, req, rb, split_base, nsplit, lane);
+          else if (nsplit == 3) combine_rows16<3>(p, req, rb, split_base, nsplit, lane);
+          else combine_rows16<0>(p, req, rb, split_base, nsplit, lane);
         }
       }
     }
@@ -799,12 +851,22 @@ int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipSt
   Params p = p_in;
   p.row_groups = (p.rows + 63) / 64;
   p.partial_bf16 = 1;   // split partials travel as bf16 rows
+  static const int merge_env = [] {   // FLUENT_MLA_MERGE_KERNEL=1: always the merge kernel; =0: always in-kernel (tests); unset: the rule below
+    const char* e = getenv("FLUENT_MLA_MERGE_KERNEL");
+    return e == nullptr ? -1 : (e[0] == '1' ? 1 : 0);
+  }();
+  // in-kernel merge when splits are rare (at least as many requests as parts: a part boundary splits at most one
+  // request, typically into 2-3 pieces); with fewer requests than parts EVERY request is cut into many pieces and the
+  // row-parallel merge kernel is the better tool
+  p.merge_in_kernel = (p.row_groups <= 6 && (merge_env == 0 || (merge_env < 0 && p.bs >= p.num_parts))) ? 1 : 0;
   const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(512);
   mla_decode_y_kernel<<<grid, block, 0, stream>>>(
-      p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, a->num_splits, (const uint8_t*)a->k_nope,
-      (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
+      p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, const_cast<int32_t*>(a->tile_scheduler_metadata), a->num_splits,
+      (const uint8_t*)a->k_nope, (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
   FL_CHECK_LAUNCH("mla_decode_y_kernel");
-  return fl_mla_launch_combine(p, a->num_splits, stream);
+  // split requests are merged inside the kernel by their last-arriving part (six 16-bit counters per part: up to 6 row
+  // groups); beyond that, or with FLUENT_MLA_MERGE_KERNEL=1, the separate merge kernel runs
+  return p.merge_in_kernel ? FL_OK : fl_mla_launch_combine(p, a->num_splits, stream);
 }
 
 #ifdef FL_MLA_TIMING

@@ -31,6 +31,7 @@ struct Params {
   float* o_accum;
   float* lse_accum;
   int partial_bf16;   // o_accum holds bf16 rows (128-row mapping) instead of f32 rows
+  int merge_in_kernel;   // mla_decode_fp8_y.hip: split requests are merged by their last-arriving part (no merge kernel)
 };
 
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -111,6 +112,103 @@ __device__ __forceinline__ void combine_row(const Params& p, const int req, cons
   if (lane == 0) {
     const int j = row / p.h_q, h = row - j * p.h_q;
     p.lse[((long long)req * p.h_q + h) * p.s_q + j] = denx > 0.f ? mxx + __logf(denx) : -INFINITY;
+  }
+}
+
+// The same merge for a BLOCK of 16 rows by one wave (in-kernel merge of mla_decode_fp8_y.hip: the merging workgroup has
+// only four waves for 64 rows, so a wave-per-row loop would be 16 dependent round trips to memory behind the fence).
+// 8 lanes per row (lane = 8*jr + q: row jr of the pass, 16-B chunks q + 8k of its 512 dims), two passes of 8 rows; per pass
+// every LSE and every partial chunk is loaded before the first use: ~3 round trips per 16 rows.  bf16 partials only.
+// NS = compile-time split count (2..4: all splits in registers); NS = 0: any count, splits streamed in pairs.
+// Every read of a partial is an AGENT-scope relaxed atomic load (sc1: served by the memory side, not by this XCD's
+// non-coherent L2) — the writers store the same way, so no cache-wide invalidate / write-back fence is needed: a
+// `__threadfence()` per split fragment invalidated the XCD's L2 under the other workgroups' page streams (measured:
+// 234 us instead of 161 on the ragged cfg2 workload).
+__device__ __forceinline__ float ld_agent_f32(const float* ptr) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent_f32(float* ptr, const float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(ptr), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent_16B(void* ptr, const uint4 v) {
+  // one 16-B store with the agent-scope cache policy (sc1: what the compiler emits for an agent-scope atomic store; the
+  // atomic builtins stop at 8 bytes).  The caller's s_waitcnt vmcnt(0) covers it.
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  const u32x4_ d = {v.x, v.y, v.z, v.w};
+  // (s_nop: a VMEM store of more than 8 bytes reads its data registers for two more cycles — the hazard recogniser does
+  //  not look inside inline asm, and the next loop iteration overwrites them)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(ptr), "v"(d) : "memory");
+}
+template <int NS>
+__device__ __forceinline__ void combine_rows16(const Params& p, const int req, const int row_base, const int s0, const int ns_rt,
+                                               const int lane) {
+  const int ns = NS > 0 ? NS : ns_rt;
+  const int jr = lane >> 3, q = lane & 7;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const uint16_t* part = reinterpret_cast<const uint16_t*>(p.o_accum);
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int row = row_base + pass * 8 + jr;
+    const bool ok = row < p.rows;
+    const int rr = ok ? row : p.rows - 1;   // (unconditional loads on a clamped row; stores are predicated)
+    float mx = -INFINITY, mxx = -INFINITY;
+    for (int s = 0; s < ns; ++s) {
+      mx = fmaxf(mx, ld_agent_f32(p.lse_accum + ((long long)(s0 + s) * p.rows + rr) * 2 + 0));
+      mxx = fmaxf(mxx, ld_agent_f32(p.lse_accum + ((long long)(s0 + s) * p.rows + rr) * 2 + 1));
+    }
+    float acc[8][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[k][i] = 0.f;
+    float den = 0.f, denx = 0.f;
+    constexpr int kChunk = NS > 0 ? NS : 2;
+    for (int c0 = 0; c0 < ns; c0 += kChunk) {
+      u32x4 ua[kChunk][8];
+      float ls[kChunk], lx[kChunk];
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) {
+        const int s = c0 + j < ns ? c0 + j : ns - 1;
+        const long long base = (long long)(s0 + s) * p.rows + rr;
+        ls[j] = ld_agent_f32(p.lse_accum + base * 2 + 0);
+        lx[j] = ld_agent_f32(p.lse_accum + base * 2 + 1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned long long* src = reinterpret_cast<const unsigned long long*>(part + base * kDN + (q + 8 * k) * 8);
+          const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ua[j][k] = u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) {
+        const bool live = c0 + j < ns;
+        const float wgt = (!live || mx == -INFINITY) ? 0.f : __expf(ls[j] - mx);
+        den += wgt;
+        denx += (!live || mxx == -INFINITY) ? 0.f : __expf(lx[j] - mxx);
+        if (live) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+              acc[k][2 * h] += wgt * __uint_as_float(ua[j][k][h] << 16);
+              acc[k][2 * h + 1] += wgt * __uint_as_float(ua[j][k][h] & 0xffff0000u);
+            }
+        }
+      }
+    }
+    const float inv = den > 0.f ? 1.f / den : 0.f;
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        *reinterpret_cast<uint4*>(p.out + ((long long)req * p.rows + row) * kDN + (q + 8 * k) * 8) =
+            make_uint4(fl_pack_bf16(acc[k][0] * inv, acc[k][1] * inv), fl_pack_bf16(acc[k][2] * inv, acc[k][3] * inv),
+                       fl_pack_bf16(acc[k][4] * inv, acc[k][5] * inv), fl_pack_bf16(acc[k][6] * inv, acc[k][7] * inv));
+      if (q == 0) {
+        const int j = row / p.h_q, h = row - j * p.h_q;
+        p.lse[((long long)req * p.h_q + h) * p.s_q + j] = denx > 0.f ? mxx + __logf(denx) : -INFINITY;
+      }
+    }
   }
 }
 

@@ -705,3 +705,20 @@ def test_replay_reference_call_trace(fm):
             assert o.shape == (bs, s_q, H, 512) and o.dtype == torch.bfloat16 and lse.shape == (bs, H, s_q), case["case"]
             assert torch.isfinite(o.float()).all(), case["case"]
             assert list(o.view(-1, H * 512).shape) == case["returned"]["shape"], case["case"]
+
+
+def test_split_merge_inside_the_decode_kernel_on_every_split_case():
+    """The role-specialised mapping merges split requests INSIDE the decode kernel (last-arriving part, mla_decode_fp8_y.hip)
+    when there are at least as many requests as parts; smaller batches take the merge kernel.  Here the parity cases, the
+    reference-jump cases and the graph-replay test of this file run once more in a process that forces the in-kernel merge
+    for every shape (FLUENT_MLA_MERGE_KERNEL=0 is read once per process), so that its counters (spare metadata columns,
+    reset by the merging part), the many-way splits (ns up to 128) and replays on unchanged metadata are all exercised."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, FLUENT_MLA_MERGE_KERNEL="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "decode_parity_vs_oracle or reference_jump or mtp_verify_and_draft or full_size_properties_cfg2_ragged"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1500:]
