@@ -159,7 +159,16 @@ def trtllm_create_ipc_workspace_for_all_reduce_fusion(rank, world_size, max_toke
     if want != "0" and torch.cuda.is_available() and (multi or want == "1"):
         from .oneshot import OneShotComm
 
-        handles[0].oneshot = OneShotComm(rank if multi else 0, world_size if multi else 1, max_token_num, hidden_dim, group=group)
+        # OneShotComm's constructor is collective and all-or-nothing: either every rank of the group is connected or every
+        # rank gets the RuntimeError (hipIpc unavailable between two devices, ...) — then the RCCL route serves every size
+        comm = None
+        try:
+            comm = OneShotComm(rank if multi else 0, world_size if multi else 1, max_token_num, hidden_dim, group=group)
+        except RuntimeError as ex:
+            import warnings
+
+            warnings.warn(f"fluent_mi355: one-shot peer-mapped C5/C6 unavailable ({ex}); using the RCCL route for every size")
+        handles[0].oneshot = comm
     return handles, tensor
 
 

@@ -40,24 +40,41 @@ class OneShotComm:
     handles in rank order (default: all_gather_object on `group`)."""
 
     def __init__(self, rank, world, max_tokens, hidden, group=None, exchange=None, timeout_s=None):
+        """Collective over the group: every rank runs the same two exchanges whether or not its local steps succeed, and
+        either all ranks end up connected or ALL raise RuntimeError (nobody is left on a different route)."""
         self.rank, self.world, self.hidden = int(rank), int(world), int(hidden)
         self.max_tokens = min(int(max_tokens), MAX_ONESHOT_TOKENS)
-        h = _vp()
-        check(lib.fl_comm_create(self.rank, self.world, self.max_tokens, self.hidden, ctypes.byref(h)), "fl_comm_create")
-        self._h = h
+        self._h = None
+        if exchange is None:
+            def exchange(obj):
+                out = [None] * self.world
+                dist.all_gather_object(out, obj, group=group)
+                return out
+        err = None
+        mine = ctypes.create_string_buffer(64)
+        try:
+            h = _vp()
+            check(lib.fl_comm_create(self.rank, self.world, self.max_tokens, self.hidden, ctypes.byref(h)), "fl_comm_create")
+            self._h = h
+            if self.world > 1:
+                check(lib.fl_comm_local_handle(self._h, ctypes.cast(mine, _vp)), "fl_comm_local_handle")
+        except RuntimeError as ex:
+            err = str(ex)
         if self.world > 1:
-            mine = ctypes.create_string_buffer(64)
-            check(lib.fl_comm_local_handle(self._h, ctypes.cast(mine, _vp)), "fl_comm_local_handle")
-            if exchange is None:
-                def exchange(b):
-                    out = [None] * self.world
-                    dist.all_gather_object(out, b, group=group)
-                    return out
-            handles = exchange(bytes(mine.raw))
-            if len(handles) != self.world or any(len(x) != 64 for x in handles):
-                raise RuntimeError("one-shot comm: the handle exchange must return one 64-byte handle per rank")
-            blob = ctypes.create_string_buffer(b"".join(handles), 64 * self.world)
-            check(lib.fl_comm_connect(self._h, ctypes.cast(blob, _vp)), "fl_comm_connect")
+            got = exchange((bytes(mine.raw), err))                       # exchange 1: handles (+ who failed so far)
+            bad = [f"rank {r}: {e}" for r, (_, e) in enumerate(got) if e is not None]
+            if not bad:
+                try:
+                    blob = ctypes.create_string_buffer(b"".join(hd for hd, _ in got), 64 * self.world)
+                    check(lib.fl_comm_connect(self._h, ctypes.cast(blob, _vp)), "fl_comm_connect")
+                except RuntimeError as ex:
+                    err = str(ex)
+                bad = [f"rank {r}: {e}" for r, e in enumerate(exchange(err)) if e is not None]   # exchange 2: who connected
+            if bad:
+                self.close()
+                raise RuntimeError("one-shot comm setup failed on " + "; ".join(bad))
+        elif err is not None:
+            raise RuntimeError(err)
         if timeout_s is not None:
             check(lib.fl_comm_set_timeout(self._h, float(timeout_s)), "fl_comm_set_timeout")
 

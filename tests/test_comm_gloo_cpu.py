@@ -176,3 +176,47 @@ def test_tpdp_convertor_inside_attention_tp_groups_world4_tp2():
 def test_comm_fusion_world2_gloo(T):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, T), nprocs=2, join=True)
+
+
+def _oneshot_setup_worker(rank, world, port):
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "sglang-fluentllm_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fluent_mi355.oneshot import OneShotComm
+
+        # no HIP device here: the local workspace allocation fails on every rank; the constructor must still run both of
+        # its exchanges and raise on ALL ranks (a rank left waiting in a collective would hang this test)
+        try:
+            OneShotComm(rank, world, 64, 256)
+            raise AssertionError("OneShotComm came up without a GPU")
+        except RuntimeError as ex:
+            assert "setup failed on rank 0" in str(ex) and "rank 1" in str(ex), str(ex)
+        # one rank fails, the other is fine so far: still both raise, naming the failing rank
+        def exchange_marker(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+        import fluent_mi355.oneshot as osm
+        orig_check = osm.check
+
+        def fake_check(status, what):   # rank 1 "succeeds" locally, rank 0 fails at create
+            if rank == 1 and what in ("fl_comm_create", "fl_comm_local_handle"):
+                return
+            orig_check(status, what)
+        osm.check = fake_check
+        try:
+            OneShotComm(rank, world, 64, 256, exchange=exchange_marker)
+            raise AssertionError("must not connect")
+        except RuntimeError as ex:
+            assert "rank 0" in str(ex) and "rank 1:" not in str(ex), str(ex)
+        finally:
+            osm.check = orig_check
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_oneshot_setup_is_all_or_nothing_across_ranks_world2_gloo():
+    port = _free_port()
+    mp.spawn(_oneshot_setup_worker, args=(2, port), nprocs=2, join=True)
