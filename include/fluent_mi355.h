@@ -211,7 +211,9 @@ int fl_ep_place_f32(const float* vals, const int32_t* pos, int64_t n, float* out
                     int64_t out_n, fl_stream_t stream);
 int fl_ep_invert(const int32_t* order, int64_t n, int32_t* inv /*inv[order[i]] = i*/, fl_stream_t stream);
 int fl_ep_gather_rows_div(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int div /*dst[i] = src[idx[i] / div]*/,
-                          int hidden, void* dst, int64_t dst_rows, fl_stream_t stream);
+                          int hidden, void* dst, int64_t dst_rows,
+                          const int32_t* n_valid /*optional DEVICE scalar: only rows i < *n_valid are copied (the launch is sized for n)*/,
+                          fl_stream_t stream);
 int fl_ep_sort(const int32_t* recv_eid /*[num_slots]*/, int64_t num_slots, int num_local_experts,
                int32_t* order /*[num_slots] slots grouped by expert, invalid last*/, int32_t* exclusive_sum /*[E_l+1]*/,
                fl_stream_t stream);

@@ -150,8 +150,10 @@ __global__ __launch_bounds__(256) void ep_sort_kernel(const int32_t* __restrict_
 template <bool kScatter>
 __global__ __launch_bounds__(256) void ep_rows_kernel(const uint16_t* __restrict__ src, const int32_t* __restrict__ idx,
                                                       long long n, int hidden, long long src_rows, long long dst_rows,
-                                                      uint16_t* __restrict__ dst, int src_div) {
+                                                      uint16_t* __restrict__ dst, int src_div,
+                                                      const int32_t* __restrict__ n_valid = nullptr) {
   const long long i = blockIdx.x;
+  if (n_valid != nullptr && i >= *n_valid) return;   // (device-side row count: the static grid covers the worst case)
   const long long j = idx[i];
   // scatter: pair i carries token i / src_div (src_div = top_k); gather: index j names pair j of row j / src_div
   const long long s = kScatter ? (long long)((unsigned)i / (unsigned)src_div) : (j < 0 ? j : j / src_div), d = kScatter ? j : i;
@@ -277,11 +279,11 @@ extern "C" int fl_ep_invert(const int32_t* order, int64_t n, int32_t* inv, fl_st
 }
 
 extern "C" int fl_ep_gather_rows_div(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int div, int hidden,
-                                     void* dst, int64_t dst_rows, fl_stream_t stream) {
+                                     void* dst, int64_t dst_rows, const int32_t* n_valid, fl_stream_t stream) {
   if (n == 0) return FL_OK;
   FL_CHECK_ARG(src && idx && dst && hidden % 8 == 0 && div >= 1, "fl_ep_gather_rows_div: bad args");
   ep_rows_kernel<false><<<dim3((unsigned)n), 256, 0, (hipStream_t)stream>>>(
-      (const uint16_t*)src, idx, n, hidden, src_rows, dst_rows, (uint16_t*)dst, div);
+      (const uint16_t*)src, idx, n, hidden, src_rows, dst_rows, (uint16_t*)dst, div, n_valid);
   FL_CHECK_LAUNCH("fl_ep_gather_rows_div");
   return FL_OK;
 }

@@ -35,7 +35,7 @@ class HipRowOps:
         lib.fl_ep_route_dedup.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp]
         lib.fl_ep_sort.argtypes = [vp, i64, i32, vp, vp, vp]
         lib.fl_ep_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
-        lib.fl_ep_gather_rows_div.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp]
+        lib.fl_ep_gather_rows_div.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp, vp]
         lib.fl_ep_scatter_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
         lib.fl_ep_send_rows.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp]
         lib.fl_ep_combine.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp]
@@ -62,10 +62,11 @@ class HipRowOps:
         self._check(self._lib.fl_ep_sort(recv_eid.data_ptr(), recv_eid.numel(), num_local_experts, order.data_ptr(),
                                          exclusive_sum.data_ptr(), self._stream(recv_eid.device)), "fl_ep_sort")
 
-    def gather_div(self, src, idx, n, div, dst):
-        """dst[i] = src[idx[i] // div] for i < n"""
+    def gather_div(self, src, idx, n, div, dst, n_valid=None):
+        """dst[i] = src[idx[i] // div] for i < min(n, n_valid[0]) (n_valid: optional int32 device scalar)"""
         self._check(self._lib.fl_ep_gather_rows_div(src.data_ptr(), src.shape[0], idx.data_ptr(), n, div, src.shape[1],
-                                                    dst.data_ptr(), dst.shape[0], self._stream(src.device)), "fl_ep_gather_rows_div")
+                                                    dst.data_ptr(), dst.shape[0], None if n_valid is None else n_valid.data_ptr(),
+                                                    self._stream(src.device)), "fl_ep_gather_rows_div")
 
     def send(self, x, send_slot, per_token, send_buf):
         """send_buf[send_slot[p]] = x[p // per_token] for every entry p with a slot"""
@@ -147,7 +148,8 @@ class AllToAll:
         order = torch.empty(S * K, dtype=torch.int32, device=dev)
         self.row_ops.sort(recv_eid, self.experts_per_rank, order, out_exclusive_sum)
         n_out = min(out_expert_x.shape[0], S * K)
-        self.row_ops.gather_div(recv_buf, order, n_out, K, out_expert_x)
+        # (static launch over the row bound; only the rows below exclusive_sum[-1] — a device value — are copied)
+        self.row_ops.gather_div(recv_buf, order, n_out, K, out_expert_x, out_exclusive_sum[self.experts_per_rank:])
         self._state = (tok_slot, pair_pos, order, n_out, S)
         return out_expert_x, out_exclusive_sum
 

@@ -39,7 +39,9 @@ class TorchRowOps:
         exclusive_sum[0] = 0
         exclusive_sum[1:] = torch.cumsum(counts, 0).to(torch.int32)
 
-    def gather_div(self, src, idx, n, div, dst):
+    def gather_div(self, src, idx, n, div, dst, n_valid=None):
+        if n_valid is not None:
+            n = min(n, int(n_valid[0]))
         i = idx[:n].long() // div
         ok = (idx[:n] >= 0) & (i < src.shape[0])
         dst[:n][ok] = src[i[ok]]

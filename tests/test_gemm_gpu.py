@@ -367,8 +367,10 @@ def test_ep_dedup_row_kernels_match_the_torch_row_ops_world4_routing():
         ops.invert(order, inv)
         src = torch.randn(W * cap, HID, generator=torch.Generator().manual_seed(6)).to(torch.bfloat16).to(dev)
         n = int(ex[-1])
-        dst = torch.zeros(n, HID, dtype=torch.bfloat16, device=dev)
-        ops.gather_div(src, order, n, K, dst)
+        dst = torch.zeros(W * cap * K, HID, dtype=torch.bfloat16, device=dev)
+        ops.gather_div(src, order, W * cap * K, K, dst, ex[EPR:])      # static launch over the row bound, device-side row count
+        assert bool((dst[n:] == 0).all())                               # rows past exclusive_sum[-1] are not touched
+        dst = dst[:n]
         outs.append([t.cpu() for t in (ts, pp, se, placed, ex)])
         # the order INSIDE an expert group is free (the device sort hands positions out with atomics): check it by meaning
         o, sec, exc = order.cpu().long(), se.cpu(), ex.cpu()
