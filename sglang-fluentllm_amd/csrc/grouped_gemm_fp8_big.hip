@@ -74,7 +74,14 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big_kernel(const Gemm
   const uint8_t* a_base = gA + row0 * p.K;
   // per-lane offsets are rebuilt per piece (2 VALU ops) from 4 registers: the row of piece k is r0 + 8k, and the
   // swizzle term (row>>1)&7 = (4k + (lane>>4))&7 takes two values (k even / odd)
-  int r0 = 32 * wave + (lane >> 3);
+#ifndef FL_GEMM_ASYM
+#define FL_GEMM_ASYM 0   // experiment (measured: 1570 vs 1584 TFLOP/s on w13 at T=16384, w2 equal — no gain): the refill of a
+                         // stage issued by ONE wave per SIMD (waves 0..3: 8 W + 8 A pieces + the scales beside the first tile of
+                         // the k block) so that the partner waves run their MFMAs during the loaders' issue stalls.  That the
+                         // per-wave LDS-DMA issue stall (~180 cycles per piece) is NOT what holds the matrix pipe at 48 % is the
+                         // finding: the k block takes the same time whoever issues the pieces
+#endif
+  int r0 = (FL_GEMM_ASYM ? 64 * (wave & 3) : 32 * wave) + (lane >> 3);
   unsigned swz0 = (((lane & 7) ^ ((lane >> 4) & 7)) << 4), swz1 = (((lane & 7) ^ ((4 + (lane >> 4)) & 7)) << 4);
   const unsigned n_last = (unsigned)p.N - 1u;                    // rows beyond N: clamped, results discarded
   const unsigned m_last = (unsigned)(row_end - row0 - 1);        // rows beyond the group: clamped, never stored
@@ -103,9 +110,15 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big_kernel(const Gemm
   };
   auto dma_piece = [&](const int kb, const int k) {   // k = 0..3: W, 4..7: A, 8: As
     uint8_t* s = stage(kb & 1);
+#if FL_GEMM_ASYM   // loader waves 0..3: k = 0..7: W pieces 8*wave + k, 8..15: A pieces, 16: As
+    if (k < 8) fl_dma16_s(uniform(w_base + (long long)kb * BK), w_off(k), s + (8 * wave + k) * 1024);
+    else if (k < 16) fl_dma16_s(uniform(a_base + (long long)kb * BK), a_off(k - 8), s + kWTile + (8 * wave + k - 8) * 1024);
+    else fl_dma4(as_src + (long long)kb * p.as_stride_k, s + kWTile + kATile + wave * 256);
+#else
     if (k < 4) fl_dma16_s(uniform(w_base + (long long)kb * BK), w_off(k), s + (4 * wave + k) * 1024);
     else if (k < 8) fl_dma16_s(uniform(a_base + (long long)kb * BK), a_off(k - 4), s + kWTile + (4 * wave + k - 4) * 1024);
     else if (wave < 4) fl_dma4(as_src + (long long)kb * p.as_stride_k, s + kWTile + kATile + wave * 256);
+#endif
   };
 
   // operand read offsets inside a 32-row x 128 B sub-tile: row li, 16-B chunk c = 4*s2 + 2*lh + e2 (s = 2*s2 + e2)
@@ -145,8 +158,15 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big_kernel(const Gemm
   const float* wsrow = gWs + ((long long)e * ((p.N + BN - 1) / BN) + (n0 + 64 * wn) / BN) * KB;
 
   // ---- prologue: stage 0 ----
+#if FL_GEMM_ASYM
+  if (wave < 4) {
+#pragma unroll
+    for (int k = 0; k < 17; ++k) dma_piece(0, k);
+  }
+#else
 #pragma unroll
   for (int k = 0; k < 9; ++k) dma_piece(0, k);
+#endif
 
 #ifdef FL_GEMM_TIMING
   unsigned long long gt[4] = {0, 0, 0, 0};
@@ -209,7 +229,12 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big_kernel(const Gemm
 #ifndef FL_GEMM_STAGGER
 #define FL_GEMM_STAGGER 1
 #endif
-#if FL_GEMM_STAGGER >= 0
+#if FL_GEMM_ASYM
+      if (t == 0 && wave < 4) {
+#pragma unroll
+        for (int k = 0; k < 17; ++k) dma_piece(kn, k);
+      }
+#elif FL_GEMM_STAGGER >= 0
       // wave pairs take turns at the CU's vector-memory path: waves 2s, 2s+1 issue their whole refill (9 pieces) beside
       // tile s = 0..3 instead of all eight waves issuing one piece beside every tile (+2.5 % on w13 at T=16384, w2 equal;
       // one wave per tile over all 8 tiles: -1.5 % — the late refills land after the next barrier)
