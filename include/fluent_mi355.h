@@ -203,20 +203,20 @@ int fl_ep_route(const int32_t* indices /*[num_pairs] global expert ids*/, int64_
                 int32_t* send_eid /*[world*cap] local expert id at the destination, -1 = empty*/, fl_stream_t stream);
 /* Token-once-per-peer routing of the same dispatch (fluent_mi355/ep.py): tok_slot [tokens, world] = the token's row in
  * each peer slab (-1: none of its experts lives there), send_eid [world*cap, top_k] = local expert ids per slab row (-1
- * padded), pair_pos [tokens, top_k] = row*top_k + j of every (token, expert) pair (where its combine weight travels). */
+ * padded), pair_src [world*cap, top_k] = t*top_k + k of the (token, expert) pair behind every slab pair (-1 padded): the
+ * layout the combine weights travel in (fl_ep_gather_f32). */
 int fl_ep_route_dedup(const int32_t* indices /*[tokens, top_k] global expert ids*/, int64_t num_tokens, int top_k,
-                      int experts_per_rank, int world, int cap, int32_t* tok_slot, int32_t* send_eid, int32_t* pair_pos,
+                      int experts_per_rank, int world, int cap, int32_t* tok_slot, int32_t* send_eid, int32_t* pair_src,
                       fl_stream_t stream);
-int fl_ep_place_f32(const float* vals, const int32_t* pos, int64_t n, float* out /*zero-filled, then out[pos[i]] = vals[i]*/,
-                    int64_t out_n, fl_stream_t stream);
-int fl_ep_invert(const int32_t* order, int64_t n, int32_t* inv /*inv[order[i]] = i*/, fl_stream_t stream);
+int fl_ep_gather_f32(const float* vals, int64_t n, const int32_t* src /*[out_n]*/, float* out /*out[j] = vals[src[j]], 0 where src[j] is not in [0, n)*/,
+                     int64_t out_n, fl_stream_t stream);
 int fl_ep_gather_rows_div(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int div /*dst[i] = src[idx[i] / div]*/,
                           int hidden, void* dst, int64_t dst_rows,
                           const int32_t* n_valid /*optional DEVICE scalar: only rows i < *n_valid are copied (the launch is sized for n)*/,
                           fl_stream_t stream);
 int fl_ep_sort(const int32_t* recv_eid /*[num_slots]*/, int64_t num_slots, int num_local_experts,
                int32_t* order /*[num_slots] slots grouped by expert, invalid last*/, int32_t* exclusive_sum /*[E_l+1]*/,
-               fl_stream_t stream);
+               int32_t* inverse /*optional [num_slots]: inverse[order[i]] = i*/, fl_stream_t stream);
 int fl_ep_gather_rows(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int hidden, void* dst,
                       int64_t dst_rows, fl_stream_t stream);   /* dst[i] = src[idx[i]] */
 int fl_ep_scatter_rows(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int hidden, void* dst,

@@ -42,13 +42,18 @@ __global__ __launch_bounds__(256) void ep_route_kernel(const int32_t* __restrict
 //   tok_slot[t, d]      slab row (d*cap + position) of token t in rank d's slab, -1 if none of its experts lives there;
 //                       positions follow the token order (deterministic)
 //   send_eid[row, j]    local expert ids of the row's token on that rank (j-th of them in k order), -1 padded
-//   pair_pos[t, k]      row*top_k + j of pair (t, k): where its combine weight goes
+//   pair_src[row, j]    t*top_k + k of the (token, expert) pair that occupies (row, j), -1 for padding: the combine
+//                       weights travel in this layout (one gather, no zero-fill pass)
 __global__ __launch_bounds__(256) void ep_route_dedup_kernel(const int32_t* __restrict__ indices, int T, int top_k,
                                                              int experts_per_rank, int world, int cap,
                                                              int32_t* __restrict__ tok_slot, int32_t* __restrict__ send_eid,
-                                                             int32_t* __restrict__ pair_pos) {
+                                                             int32_t* __restrict__ pair_src) {
   extern __shared__ unsigned long long s_mask[];   // [T] peers of every token (world <= 64)
-  for (long long i = threadIdx.x; i < (long long)world * cap * top_k; i += 256) send_eid[i] = -1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long long i = threadIdx.x; i < (long long)world * cap * top_k; i += 256) {
+    send_eid[i] = -1;
+    pair_src[i] = -1;
+  }
   for (int t = threadIdx.x; t < T; t += 256) {
     unsigned long long m = 0;
     for (int k = 0; k < top_k; ++k) {
@@ -58,21 +63,22 @@ __global__ __launch_bounds__(256) void ep_route_dedup_kernel(const int32_t* __re
     s_mask[t] = m;
   }
   __syncthreads();
-  if ((int)threadIdx.x < world) {   // peer d: positions in token order
-    const int d = threadIdx.x;
-    int pos = 0;
-    for (int t = 0; t < T; ++t) {
-      const bool on = (s_mask[t] >> d) & 1ull;
-      tok_slot[t * world + d] = (on && pos < cap) ? d * cap + pos : -1;
-      pos += on ? 1 : 0;
+  // slab positions in token order: peer d is scanned by wave d % 4, 64 tokens per step (ballot + prefix popcount)
+  for (int d = wave; d < world; d += 4) {
+    int run = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int t = t0 + lane;
+      const bool on = t < T && ((s_mask[t < T ? t : 0] >> d) & 1ull);
+      const unsigned long long b = __ballot(on);
+      const int pos = run + __popcll(b & ((1ull << lane) - 1ull));
+      if (t < T) tok_slot[t * world + d] = (on && pos < cap) ? d * cap + pos : -1;
+      run += __popcll(b);
     }
   }
-  __syncthreads();
-  __threadfence_block();
+  __syncthreads();   // (tok_slot is re-read below by other threads of this workgroup: global writes of the workgroup are visible behind the barrier)
   for (int t = threadIdx.x; t < T; t += 256) {
     for (int k = 0; k < top_k; ++k) {
       const int e = indices[t * top_k + k];
-      int pp = -1;
       if (e >= 0 && e < experts_per_rank * world) {
         const int d = e / experts_per_rank;
         const int row = tok_slot[t * world + d];
@@ -83,40 +89,26 @@ __global__ __launch_bounds__(256) void ep_route_dedup_kernel(const int32_t* __re
             j += (e2 >= 0 && e2 < experts_per_rank * world && e2 / experts_per_rank == d) ? 1 : 0;
           }
           send_eid[(long long)row * top_k + j] = e - d * experts_per_rank;
-          pp = row * top_k + j;
+          pair_src[(long long)row * top_k + j] = t * top_k + k;
         }
       }
-      pair_pos[t * top_k + k] = pp;
     }
   }
 }
 
-// out[pos[i]] = vals[i] (pos < 0: skipped); out was zero-filled by the caller's kernel below
-__global__ __launch_bounds__(256) void ep_place_f32_kernel(const float* __restrict__ vals, const int32_t* __restrict__ pos,
-                                                           long long n, long long out_n, float* __restrict__ out) {
-  const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
-  for (long long i = i0; i < out_n; i += (long long)gridDim.x * 256) out[i] = 0.f;
-}
-__global__ __launch_bounds__(256) void ep_place_f32_kernel2(const float* __restrict__ vals, const int32_t* __restrict__ pos,
-                                                            long long n, long long out_n, float* __restrict__ out) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) {
-    const long long p = pos[i];
-    if (p >= 0 && p < out_n) out[p] = vals[i];
-  }
-}
-
-// inv[order[i]] = i for i < n (the position of every slot in the sorted order)
-__global__ __launch_bounds__(256) void ep_invert_kernel(const int32_t* __restrict__ order, long long n, int32_t* __restrict__ inv) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) {
-    const long long o = order[i];
-    if (o >= 0 && o < n) inv[o] = (int32_t)i;
+// out[j] = vals[src[j]] where src[j] names a value (0 <= src[j] < n), else 0: the combine weights in the slab-pair layout
+__global__ __launch_bounds__(256) void ep_gather_f32_kernel(const float* __restrict__ vals, long long n, const int32_t* __restrict__ src,
+                                                            long long out_n, float* __restrict__ out) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j < out_n) {
+    const long long i = src[j];
+    out[j] = (i >= 0 && i < n) ? vals[i] : 0.f;
   }
 }
 
 __global__ __launch_bounds__(256) void ep_sort_kernel(const int32_t* __restrict__ recv_eid, int S, int E,
-                                                      int32_t* __restrict__ order, int32_t* __restrict__ exclusive_sum) {
+                                                      int32_t* __restrict__ order, int32_t* __restrict__ exclusive_sum,
+                                                      int32_t* __restrict__ inv /*optional: inv[order[i]] = i*/) {
   extern __shared__ int bins[];   // E + 1 counters, then E + 1 cursors
   int* cur = bins + E + 1;
   for (int i = threadIdx.x; i <= E; i += 256) bins[i] = 0;
@@ -142,6 +134,7 @@ __global__ __launch_bounds__(256) void ep_sort_kernel(const int32_t* __restrict_
     const int e = recv_eid[i];
     const int pos = atomicAdd(&cur[(e >= 0 && e < E) ? e : E], 1);
     order[pos] = i;   // invalid slots end up after every valid row
+    if (inv != nullptr) inv[i] = pos;
   }
 }
 
@@ -250,31 +243,21 @@ extern "C" int fl_ep_route(const int32_t* indices, int64_t num_pairs, int expert
 }
 
 extern "C" int fl_ep_route_dedup(const int32_t* indices, int64_t num_tokens, int top_k, int experts_per_rank, int world, int cap,
-                                 int32_t* tok_slot, int32_t* send_eid, int32_t* pair_pos, fl_stream_t stream) {
-  FL_CHECK_ARG(send_eid && (num_tokens == 0 || (indices && tok_slot && pair_pos)), "fl_ep_route_dedup: null pointer");
+                                 int32_t* tok_slot, int32_t* send_eid, int32_t* pair_src, fl_stream_t stream) {
+  FL_CHECK_ARG(send_eid && pair_src && (num_tokens == 0 || (indices && tok_slot)), "fl_ep_route_dedup: null pointer");
   FL_CHECK_ARG(world >= 1 && world <= 64 && cap >= 1 && experts_per_rank >= 1 && top_k >= 1 && num_tokens >= 0 &&
                    num_tokens <= 8192, "fl_ep_route_dedup: bad sizes (tokens per rank <= 8192, world <= 64)");
   ep_route_dedup_kernel<<<1, 256, (size_t)(num_tokens > 0 ? num_tokens : 1) * 8, (hipStream_t)stream>>>(
-      indices, (int)num_tokens, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_pos);
+      indices, (int)num_tokens, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_src);
   FL_CHECK_LAUNCH("fl_ep_route_dedup");
   return FL_OK;
 }
 
-extern "C" int fl_ep_place_f32(const float* vals, const int32_t* pos, int64_t n, float* out, int64_t out_n, fl_stream_t stream) {
-  FL_CHECK_ARG(out_n >= 0 && n >= 0 && (out || out_n == 0) && (n == 0 || (vals && pos)), "fl_ep_place_f32: bad args");
+extern "C" int fl_ep_gather_f32(const float* vals, int64_t n, const int32_t* src, float* out, int64_t out_n, fl_stream_t stream) {
+  FL_CHECK_ARG(out_n >= 0 && n >= 0 && (out_n == 0 || (out && src)) && (n == 0 || vals), "fl_ep_gather_f32: bad args");
   if (out_n == 0) return FL_OK;
-  const long long zb = (out_n + 255) / 256;
-  ep_place_f32_kernel<<<dim3((unsigned)(zb < 1024 ? zb : 1024)), 256, 0, (hipStream_t)stream>>>(vals, pos, n, out_n, out);
-  if (n > 0) ep_place_f32_kernel2<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(vals, pos, n, out_n, out);
-  FL_CHECK_LAUNCH("fl_ep_place_f32");
-  return FL_OK;
-}
-
-extern "C" int fl_ep_invert(const int32_t* order, int64_t n, int32_t* inv, fl_stream_t stream) {
-  if (n == 0) return FL_OK;
-  FL_CHECK_ARG(order && inv && n > 0, "fl_ep_invert: bad args");
-  ep_invert_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(order, n, inv);
-  FL_CHECK_LAUNCH("fl_ep_invert");
+  ep_gather_f32_kernel<<<dim3((unsigned)((out_n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(vals, n, src, out_n, out);
+  FL_CHECK_LAUNCH("fl_ep_gather_f32");
   return FL_OK;
 }
 
@@ -289,11 +272,11 @@ extern "C" int fl_ep_gather_rows_div(const void* src, int64_t src_rows, const in
 }
 
 extern "C" int fl_ep_sort(const int32_t* recv_eid, int64_t num_slots, int num_local_experts, int32_t* order,
-                          int32_t* exclusive_sum, fl_stream_t stream) {
+                          int32_t* exclusive_sum, int32_t* inverse, fl_stream_t stream) {
   FL_CHECK_ARG(recv_eid && order && exclusive_sum, "fl_ep_sort: null pointer");
   FL_CHECK_ARG(num_local_experts >= 1 && num_local_experts <= 4096 && num_slots >= 0, "fl_ep_sort: bad sizes");
   ep_sort_kernel<<<1, 256, 2 * (num_local_experts + 1) * sizeof(int), (hipStream_t)stream>>>(
-      recv_eid, (int)num_slots, num_local_experts, order, exclusive_sum);
+      recv_eid, (int)num_slots, num_local_experts, order, exclusive_sum, inverse);
   FL_CHECK_LAUNCH("fl_ep_sort");
   return FL_OK;
 }

@@ -33,16 +33,15 @@ class HipRowOps:
         vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
         lib.fl_ep_route.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp]
         lib.fl_ep_route_dedup.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp]
-        lib.fl_ep_sort.argtypes = [vp, i64, i32, vp, vp, vp]
+        lib.fl_ep_sort.argtypes = [vp, i64, i32, vp, vp, vp, vp]
         lib.fl_ep_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
         lib.fl_ep_gather_rows_div.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp, vp]
         lib.fl_ep_scatter_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
         lib.fl_ep_send_rows.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp]
         lib.fl_ep_combine.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp]
-        lib.fl_ep_place_f32.argtypes = [vp, vp, i64, vp, i64, vp]
-        lib.fl_ep_invert.argtypes = [vp, i64, vp, vp]
+        lib.fl_ep_gather_f32.argtypes = [vp, i64, vp, vp, i64, vp]
         for n in ("fl_ep_route", "fl_ep_route_dedup", "fl_ep_sort", "fl_ep_gather_rows", "fl_ep_gather_rows_div",
-                  "fl_ep_scatter_rows", "fl_ep_send_rows", "fl_ep_combine", "fl_ep_place_f32", "fl_ep_invert"):
+                  "fl_ep_scatter_rows", "fl_ep_send_rows", "fl_ep_combine", "fl_ep_gather_f32"):
             getattr(lib, n).restype = i32
 
     @staticmethod
@@ -53,14 +52,15 @@ class HipRowOps:
             raise RuntimeError("expected a CUDA/HIP tensor")
         return stream_ptr(t.device)
 
-    def route_dedup(self, indices, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_pos):
+    def route_dedup(self, indices, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_src):
         self._check(self._lib.fl_ep_route_dedup(indices.data_ptr(), indices.numel() // top_k, top_k, experts_per_rank, world, cap,
-                                                tok_slot.data_ptr(), send_eid.data_ptr(), pair_pos.data_ptr(),
+                                                tok_slot.data_ptr(), send_eid.data_ptr(), pair_src.data_ptr(),
                                                 self._stream(send_eid.device)), "fl_ep_route_dedup")
 
-    def sort(self, recv_eid, num_local_experts, order, exclusive_sum):
+    def sort(self, recv_eid, num_local_experts, order, exclusive_sum, inverse=None):
         self._check(self._lib.fl_ep_sort(recv_eid.data_ptr(), recv_eid.numel(), num_local_experts, order.data_ptr(),
-                                         exclusive_sum.data_ptr(), self._stream(recv_eid.device)), "fl_ep_sort")
+                                         exclusive_sum.data_ptr(), None if inverse is None else inverse.data_ptr(),
+                                         self._stream(recv_eid.device)), "fl_ep_sort")
 
     def gather_div(self, src, idx, n, div, dst, n_valid=None):
         """dst[i] = src[idx[i] // div] for i < min(n, n_valid[0]) (n_valid: optional int32 device scalar)"""
@@ -79,13 +79,10 @@ class HipRowOps:
                                             out.shape[0], per_token, out.shape[1], out.data_ptr(), self._stream(out.device)),
                     "fl_ep_combine")
 
-    def place_f32(self, vals, pos, out):
-        """out = 0; out[pos[i]] = vals[i]"""
-        self._check(self._lib.fl_ep_place_f32(vals.data_ptr(), pos.data_ptr(), vals.numel(), out.data_ptr(), out.numel(),
-                                              self._stream(out.device)), "fl_ep_place_f32")
-
-    def invert(self, order, inv):
-        self._check(self._lib.fl_ep_invert(order.data_ptr(), order.numel(), inv.data_ptr(), self._stream(order.device)), "fl_ep_invert")
+    def gather_f32(self, vals, src, out):
+        """out[j] = vals[src[j]] where src[j] names a value, else 0"""
+        self._check(self._lib.fl_ep_gather_f32(vals.data_ptr(), vals.numel(), src.data_ptr(), out.data_ptr(), out.numel(),
+                                               self._stream(out.device)), "fl_ep_gather_f32")
 
 
 class AllToAll:
@@ -137,26 +134,27 @@ class AllToAll:
         S = W * self.cap
         idx = indices.reshape(-1).contiguous()
         tok_slot = torch.empty(t * W, dtype=torch.int32, device=dev)
-        pair_pos = torch.empty(t * K, dtype=torch.int32, device=dev)
+        pair_src = torch.empty(S * K, dtype=torch.int32, device=dev)
         send_eid = torch.empty(S * K, dtype=torch.int32, device=dev)
-        self.row_ops.route_dedup(idx, K, self.experts_per_rank, W, self.cap, tok_slot, send_eid, pair_pos)
+        self.row_ops.route_dedup(idx, K, self.experts_per_rank, W, self.cap, tok_slot, send_eid, pair_src)
         send_buf = torch.empty(S, self.hidden, dtype=dp_x.dtype, device=dev)   # empty rows: never read (all their eids are -1)
         self.row_ops.send(dp_x.contiguous(), tok_slot, W, send_buf)
         recv_buf = self._a2a(send_buf)
         recv_eid = self._a2a(send_eid)
         # received (row, j) pairs grouped by local expert; a row with several local experts is replicated HERE
         order = torch.empty(S * K, dtype=torch.int32, device=dev)
-        self.row_ops.sort(recv_eid, self.experts_per_rank, order, out_exclusive_sum)
+        inv = torch.empty(S * K, dtype=torch.int32, device=dev)      # position of every received pair in the sorted rows (combine)
+        self.row_ops.sort(recv_eid, self.experts_per_rank, order, out_exclusive_sum, inv)
         n_out = min(out_expert_x.shape[0], S * K)
         # (static launch over the row bound; only the rows below exclusive_sum[-1] — a device value — are copied)
         self.row_ops.gather_div(recv_buf, order, n_out, K, out_expert_x, out_exclusive_sum[self.experts_per_rank:])
-        self._state = (tok_slot, pair_pos, order, n_out, S)
+        self._state = (tok_slot, pair_src, inv, n_out, S)
         return out_expert_x, out_exclusive_sum
 
     def combine(self, out_tokens, weights, expert_y, num_global_tokens):
         if self._state is None:
             raise RuntimeError("combine() without a preceding dispatch()")
-        tok_slot, pair_pos, order, n_out, S = self._state
+        tok_slot, pair_src, inv, n_out, S = self._state
         dev, W, K = expert_y.device, self.world, self.top_k
         if expert_y.element_size() != 2 or expert_y.shape[1] != self.hidden:
             raise RuntimeError(f"AllToAll.combine: expert_y must be a 2-byte [rows, {self.hidden}] tensor")
@@ -164,12 +162,10 @@ class AllToAll:
             raise RuntimeError("AllToAll.combine: weights must hold tokens x top_k values")
         # the pairs' weights travel to the expert ranks in the layout of the expert ids (0 where a row has no j-th expert)
         send_w = torch.empty(S * K, dtype=torch.float32, device=dev)
-        self.row_ops.place_f32(weights.to(torch.float32).reshape(-1).contiguous(), pair_pos, send_w)
+        self.row_ops.gather_f32(weights.to(torch.float32).reshape(-1).contiguous(), pair_src, send_w)
         recv_w = self._a2a(send_w)
         # expert rank: ONE row per received token = weighted sum over its local experts (rows nobody computed — pairs beyond
         # expert_y — and empty slab rows contribute nothing: their weight is 0 / their position is out of range)
-        inv = torch.full((S * K,), -1, dtype=torch.int32, device=dev)
-        self.row_ops.invert(order, inv)
         back = torch.empty(S, self.hidden, dtype=expert_y.dtype, device=dev)
         self.row_ops.combine(expert_y[:n_out] if n_out < expert_y.shape[0] else expert_y, inv, recv_w, back, K)
         ret = self._a2a(back)

@@ -5,8 +5,9 @@ import torch
 
 
 class TorchRowOps:
-    def route_dedup(self, indices, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_pos):
+    def route_dedup(self, indices, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_src):
         send_eid.fill_(-1)
+        pair_src.fill_(-1)
         ids = indices.view(-1, top_k).tolist()
         T = len(ids)
         ts = [[-1] * world for _ in range(T)]
@@ -20,24 +21,24 @@ class TorchRowOps:
         for t in range(T):
             seen = [0] * world
             for k, e in enumerate(ids[t]):
-                pp = -1
                 if 0 <= e < experts_per_rank * world:
                     d = e // experts_per_rank
                     row = ts[t][d]
                     if row >= 0:
                         send_eid[row * top_k + seen[d]] = e - d * experts_per_rank
-                        pp = row * top_k + seen[d]
+                        pair_src[row * top_k + seen[d]] = t * top_k + k
                     seen[d] += 1
-                pair_pos[t * top_k + k] = pp
         if T:
             tok_slot.copy_(torch.tensor(ts, dtype=torch.int32).view(-1))
 
-    def sort(self, recv_eid, E, order, exclusive_sum):
+    def sort(self, recv_eid, E, order, exclusive_sum, inverse=None):
         key = torch.where((recv_eid >= 0) & (recv_eid < E), recv_eid, torch.full_like(recv_eid, E))
         order.copy_(torch.argsort(key, stable=True).to(torch.int32))
         counts = torch.bincount(key.long(), minlength=E + 1)[:E]
         exclusive_sum[0] = 0
         exclusive_sum[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        if inverse is not None:
+            inverse[order.long()] = torch.arange(order.numel(), dtype=torch.int32)
 
     def gather_div(self, src, idx, n, div, dst, n_valid=None):
         if n_valid is not None:
@@ -58,10 +59,6 @@ class TorchRowOps:
         r = torch.where(ok, rows[s.clamp(0, max(rows.shape[0] - 1, 0))].float(), torch.zeros(())) if rows.shape[0] else torch.zeros(s.shape + (out.shape[1],))
         out.copy_((r * w.unsqueeze(-1)).sum(1).to(out.dtype))
 
-    def place_f32(self, vals, pos, out):
-        out.zero_()
-        ok = pos >= 0
-        out[pos[ok].long()] = vals[ok]
-
-    def invert(self, order, inv):
-        inv[order.long()] = torch.arange(order.numel(), dtype=torch.int32)
+    def gather_f32(self, vals, src, out):
+        ok = (src >= 0) & (src < vals.numel())
+        out.copy_(torch.where(ok, vals[src.clamp(0, max(vals.numel() - 1, 0)).long()] if vals.numel() else torch.zeros(src.numel()), torch.zeros(())))

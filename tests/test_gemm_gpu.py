@@ -337,7 +337,7 @@ def test_ep_all_to_all_single_rank_hip_row_ops():
 
 
 def test_ep_dedup_row_kernels_match_the_torch_row_ops_world4_routing():
-    """The token-once-per-peer routing kernels (route_dedup / place_f32 / invert / gather_div) against the torch-indexing
+    """The token-once-per-peer routing kernels (route_dedup / gather_f32 / sort with inverse / gather_div) against the torch-indexing
     implementation the gloo tests inject, with the routing of a 4-rank job (no exchange needed to compare the kernels)."""
     import os
     import sys
@@ -354,17 +354,16 @@ def test_ep_dedup_row_kernels_match_the_torch_row_ops_world4_routing():
     outs = []
     for ops, dev in ((ref, "cpu"), (hip, DEV)):
         ts = torch.empty(T * W, dtype=torch.int32, device=dev)
-        pp = torch.empty(T * K, dtype=torch.int32, device=dev)
+        pp = torch.empty(W * cap * K, dtype=torch.int32, device=dev)   # pair_src: the (token, k) behind every slab pair
         se = torch.empty(W * cap * K, dtype=torch.int32, device=dev)
         ops.route_dedup(idx.to(dev).reshape(-1), K, EPR, W, cap, ts, se, pp)
         vals = torch.rand(T * K, generator=torch.Generator().manual_seed(5)).to(dev)
         placed = torch.empty(W * cap * K, dtype=torch.float32, device=dev)
-        ops.place_f32(vals, pp, placed)
+        ops.gather_f32(vals, pp, placed)
         order = torch.empty(W * cap * K, dtype=torch.int32, device=dev)
         ex = torch.empty(EPR + 1, dtype=torch.int32, device=dev)
-        ops.sort(se, EPR, order, ex)
         inv = torch.full((W * cap * K,), -1, dtype=torch.int32, device=dev)
-        ops.invert(order, inv)
+        ops.sort(se, EPR, order, ex, inv)
         src = torch.randn(W * cap, HID, generator=torch.Generator().manual_seed(6)).to(torch.bfloat16).to(dev)
         n = int(ex[-1])
         dst = torch.zeros(W * cap * K, HID, dtype=torch.bfloat16, device=dev)
