@@ -883,7 +883,7 @@ extern "C" int fl_mla_workspace_bytes(int kv_format, int bs, int s_q, int h_q, i
     return !(e != nullptr && e[0] == '0');
   }();
   bool bf16_partials = false;
-  if (kv_format == FL_KV_FP8_PER_TOKEN && fl_mla_use_y() && rows > 32) bf16_partials = true;
+  if (kv_format != FL_KV_BF16_576 && fl_mla_use_y() && rows > 32) bf16_partials = true;
   else if (kv_format != FL_KV_BF16_576 && fl_mla_use_x() && (rows > 64 || (x_small && rows > 32))) bf16_partials = true;
   *o_accum_bytes = (long long)(bs + num_parts) * rows * 512 * (bf16_partials ? 2 : 4);
   *lse_accum_bytes = (long long)(bs + num_parts) * rows * 2 * 4;
@@ -917,7 +917,8 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   // 85.8 us) where this file's two half-waves + two loaders take 78.3.  FLUENT_MLA_X=0: this file for every shape.
   // fl_mla_num_parts sizes the scheduler's part count with the same rule.
   // Role-specialised 64-row workgroups (mla_decode_fp8_y.hip): per-token FP8, more than 32 query rows per request.
-  if (per_token && fl_mla_use_y() && p.rows > 32) return fl_mla_decode_fp8_y_impl(a, p, stream);
+  // (both fp8 formats: the plain [.,576] cache is the kernel's FMT = 1 instantiation)
+  if (fl_mla_use_y() && p.rows > 32) return fl_mla_decode_fp8_y_impl(a, p, stream);
   static const bool x_small = [] {
     const char* e = getenv("FLUENT_MLA_X_SMALL");
     return !(e != nullptr && e[0] == '0');

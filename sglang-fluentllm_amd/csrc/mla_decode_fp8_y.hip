@@ -86,8 +86,11 @@ struct PvLane {
 };
 // byte offset inside the page of this lane's 16 B of latent piece k of this wave (2 token rows of 512 B per piece, chunk c
 // of token T stored at chunk c ^ (T & 15))
+// (FMT 1: the plain-fp8 cache has 576-B token rows — two rows of a piece are 1152 source bytes apart; the destination in LDS
+//  is the same 512-B-row slot: only the latent part of a row is staged, the row's rope bytes go to registers)
+template <int FMT>
 __device__ __forceinline__ unsigned dn_off(const PvLane& lc, const int k) {
-  return lc.dn_row + (unsigned)k * 1024u + (lc.dn_x ^ ((unsigned)k << 5));
+  return lc.dn_row + (unsigned)k * (FMT == 1 ? 1152u : 1024u) + (lc.dn_x ^ ((unsigned)k << 5));
 }
 
 // scale triples {ks, log2 ks, 1/ks} of a QK wave's 32 tokens (lane li = token 32W + li) -> wave-private scratch
@@ -345,7 +348,7 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
 // a reference more than kMaxUp above m_o cannot be represented: it raises `redo` and the workgroup repeats the request
 // with m_o preset to the final reference.
 constexpr float kMaxUp = 64.f;
-template <bool DMA>
+template <bool DMA, int FMT>
 __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, const PvLane& lc_in, const int lane,
                                         const uint8_t* __restrict__ vp, const uint8_t* __restrict__ pbuf_rt,
                                         const float* __restrict__ ref_rt, const uint8_t* __restrict__ src_nope,
@@ -368,7 +371,7 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, con
 #if !defined(FL_Y_NODMA) && !defined(FL_Y_NOPV)
   if (DMA) {
 #pragma unroll
-    for (int k = 0; k < FL_Y_DMA_FIRST; ++k) fl_dma16_s(src_nope, dn_off(lc, k), dma_dst + k * 1024);
+    for (int k = 0; k < FL_Y_DMA_FIRST; ++k) fl_dma16_s(src_nope, dn_off<FMT>(lc, k), dma_dst + k * 1024);
   }
 #endif
   v8i va[8];
@@ -390,7 +393,7 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, con
 #ifdef FL_Y_NOPV   // experiment: PV waves without V^T reads and MFMAs (results are garbage)
   if (DMA) {
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb) fl_dma16_s(src_nope, dn_off(lc, jb), dma_dst + jb * 1024);
+    for (int jb = 0; jb < 8; ++jb) fl_dma16_s(src_nope, dn_off<FMT>(lc, jb), dma_dst + jb * 1024);
   }
   m_o = fmaxf(m_o, m0 + m1 + __uint_as_float(p0.x ^ p1.x));
   return;
@@ -410,7 +413,7 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, con
     if (jb + 3 < 8) load_vt(jb + 3);
     o[jb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[jb], pb, o[jb], 0, 0, 0, kUnitScale, 0, sb);
 #if !defined(FL_Y_NODMA)
-    if (DMA && jb >= FL_Y_DMA_FIRST) fl_dma16_s(src_nope, dn_off(lc, jb), dma_dst + jb * 1024);
+    if (DMA && jb >= FL_Y_DMA_FIRST) fl_dma16_s(src_nope, dn_off<FMT>(lc, jb), dma_dst + jb * 1024);
 #endif
   }
   // V^T operand reads three tiles ahead of their MFMA
@@ -424,6 +427,96 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, con
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- QK wave, plain-fp8 [.,576] format (FL_KV_FP8_576, flash_mla_with_kvcache over an fp8 cache): the 64 rope dims are a
+//      NINTH fp8 k-step whose A operand comes straight from bytes 512..575 of the token's row in global memory (two pages
+//      ahead, like the bf16 rope of the per-token format); there are no per-token scales — the device-scalar descales are
+//      folded into qs (scores) and into the epilogue (V).  Same block-reference / P' arithmetic as qk_step. ----
+__device__ __forceinline__ void qk_step1(float& l_run, float& lq_run, float& m_w, const QkLane& lc, const int lane,
+                                         const v8i (&qn)[8], const v8i& qr8, const float qs, RopeRegs& rr,
+                                         const uint8_t* __restrict__ rope_next, const uint8_t* __restrict__ kp,
+                                         uint8_t* __restrict__ pbuf_w, float* __restrict__ ref_w, const int tok0w,
+                                         const int L_row, const bool need_mask) {
+  const int li = lane & 31, lh = lane >> 5;
+  __builtin_amdgcn_s_setprio(1);
+  v16f acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  uint4 ka[8][2];
+  int kb0 = lc.kb0;
+  asm volatile("" : "+v"(kb0));
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    ka[s][0] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6)) + (s >> 2) * 256);
+    ka[s][1] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6) ^ 16) + (s >> 2) * 256);
+  }
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(rr.ra[0], rr.ra[1]), qr8, acc, 0, 0, 0, kUnitScale, 0, kUnitScale);
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc, 0, 0, 0, kUnitScale, 0,
+                                                          kUnitScale);
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    // DS reads: k-steps 0..3
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // rope k-step
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(0);
+  // rope bytes of page i+2 into the registers the rope MFMA has read (UNCONDITIONAL, the caller clamps the page)
+  rr.ra[0] = *reinterpret_cast<const uint4*>(rope_next);
+  rr.ra[1] = *reinterpret_cast<const uint4*>(rope_next + 16);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- online softmax of the block; tokens of lane: 32W + 8g + 4lh + e ----
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int tb = g * 8 + lh * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float y = acc[g * 4 + e] * qs;
+      if (need_mask) {
+        if (tok0w + tb + e >= L_row) y = -INFINITY;
+        if (!(y == y)) y = -INFINITY;   // NaN can only come from garbage beyond the row's limit
+      }
+      acc[g * 4 + e] = y;
+      tmax = fmaxf(tmax, y);
+    }
+  }
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+    tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  }
+  const float m_new = tmax > m_w ? ceilf(tmax) + kRefHeadroom : m_w;
+  const float moff = kPShift - m_new;
+  float ev[16];
+  int pk[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ev[g * 4 + e] = __builtin_amdgcn_exp2f(acc[g * 4 + e] + moff);
+    const int v = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 0], ev[g * 4 + 1], 0, false);
+    pk[g] = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 2], ev[g * 4 + 3], v, true);
+  }
+  *reinterpret_cast<uint4*>(pbuf_w + lane * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  ref_w[li] = m_new;
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const float f = __builtin_amdgcn_exp2f(m_w - m_new);
+    float2v l2 = {l_run * f, 0.f}, q2 = {lq_run * f, 0.f};
+    m_w = m_new;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      l2 = l2 + float2v{ev[g * 4 + 0], ev[g * 4 + 1]} + float2v{ev[g * 4 + 2], ev[g * 4 + 3]};
+      q2 = q2 + __builtin_amdgcn_cvt_pk_f32_fp8(pk[g], false) + __builtin_amdgcn_cvt_pk_f32_fp8(pk[g], true);
+    }
+    l_run = l2[0] + l2[1];
+    lq_run = q2[0] + q2[1];
+  }
+}
+
+template <int FMT>
 __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const Params p, const int32_t* __restrict__ g_block_table, const int32_t* __restrict__ g_seqlens,
     const int32_t* __restrict__ g_meta, int32_t* g_merge_ctr, const int32_t* __restrict__ g_num_splits,
@@ -508,23 +601,32 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       // Q fragments (B operands), once per request
       const long long qrow = (long long)req * p.rows + row;
       v8i qn[8];
+      v8i qr8 = v8i{0, 0, 0, 0, 0, 0, 0, 0};   // FMT 1: the rope k-step of Q (fp8)
       uint8_t* qr_lds = smem + kOffQr + w4 * 4096;
       float qs = 0.f;
+      constexpr int kQRow = FMT == 1 ? kDN + kDR : kDN;   // bytes per query row (FMT 1: one fp8 [.,576] tensor)
       if (row_ok) {
-        const uint8_t* qp = g_q_nope + qrow * kDN + lh * 32;
+        const uint8_t* qp = g_q_nope + qrow * kQRow + lh * 32;
 #pragma unroll
         for (int s = 0; s < 8; ++s)
           qn[s] = make_v8i(*reinterpret_cast<const uint4*>(qp + s * 64), *reinterpret_cast<const uint4*>(qp + s * 64 + 16));
-        const uint16_t* rp = g_q_rope + qrow * kDR + lh * 8;
+        if constexpr (FMT == 1) {
+          qr8 = make_v8i(*reinterpret_cast<const uint4*>(qp + 512), *reinterpret_cast<const uint4*>(qp + 512 + 16));
+          qs = (p.descale_q ? *p.descale_q : 1.f) * (p.descale_k ? *p.descale_k : 1.f) * p.scale_log2e;
+        } else {
+          const uint16_t* rp = g_q_rope + qrow * kDR + lh * 8;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          *reinterpret_cast<uint4*>(qr_lds + s * 1024 + lane * 16) = *reinterpret_cast<const uint4*>(rp + s * 16);
-        qs = g_q_scale[qrow] * p.scale_log2e;
+          for (int s = 0; s < 4; ++s)
+            *reinterpret_cast<uint4*>(qr_lds + s * 1024 + lane * 16) = *reinterpret_cast<const uint4*>(rp + s * 16);
+          qs = g_q_scale[qrow] * p.scale_log2e;
+        }
       } else {
 #pragma unroll
         for (int s = 0; s < 8; ++s) qn[s] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (FMT == 0) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<uint4*>(qr_lds + s * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+          for (int s = 0; s < 4; ++s) *reinterpret_cast<uint4*>(qr_lds + s * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+        }
       }
       int L_row = L;
       if (p.causal) L_row = L - (p.s_q - 1 - row / p.h_q);   // query j sees keys [0, L - (s_q-1-j))
@@ -537,14 +639,22 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
 #ifdef FL_Y_ROPE1LINE   // experiment: every lane reads the same 32 B of the page (one 128-B line per instruction; results are garbage)
         return reinterpret_cast<const uint8_t*>(g_k_rope) + (page_of(t) * kPage + 32 * W) * (kDR * 2) + lh * 16;
 #endif
+        if constexpr (FMT == 1)   // bytes 512 + 32 lh .. of the token's 576-B row: the rope k-step's A operand
+          return g_k_nope + (page_of(t) * kPage + 32 * W + li) * (long long)(kDN + kDR) + kDN + lh * 32;
         return reinterpret_cast<const uint8_t*>(g_k_rope) + (page_of(t) * kPage + 32 * W + li) * (kDR * 2) + lh * 16;
       };
       auto scale_src = [&](const int t) { return g_k_scale + page_of(t) * kPage + 32 * W + li; };
       auto load_rope = [&](RopeRegs& r, const int t) {
         const uint8_t* rp = rope_src(t);
+        if constexpr (FMT == 1) {
+          r.ra[0] = *reinterpret_cast<const uint4*>(rp);
+          r.ra[1] = *reinterpret_cast<const uint4*>(rp + 16);
+          r.ks = 1.f;
+        } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) r.ra[s] = *reinterpret_cast<const uint4*>(rp + s * 32);
-        r.ks = *scale_src(t);
+          for (int s = 0; s < 4; ++s) r.ra[s] = *reinterpret_cast<const uint4*>(rp + s * 32);
+          r.ks = *scale_src(t);
+        }
         r.pf = 0;
       };
       for (int pass = 0; pass < 2; ++pass) {
@@ -553,7 +663,8 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
         if (pass == 1) load_window(0);
         load_rope(rA, 0);
         load_rope(rB, n > 1 ? 1 : 0);
-        scale_prep(scratch, rA.ks, tile_b * kPage + 32 * W, li, L);   // page 0 -> parity 0 (this wave's reads of the previous request are done)
+        if constexpr (FMT == 0)
+          scale_prep(scratch, rA.ks, tile_b * kPage + 32 * W, li, L);   // page 0 -> parity 0 (this wave's reads of the previous request are done)
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // R0: every wave is done with the LDS of the previous request / pass
@@ -564,7 +675,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           if (i + 2 >= win_base + 64 && i + 2 < n) load_window(i + 2);   // pages i+2 .. i+65
           const int t2 = i + 2 < n ? i + 2 : n - 1;
           const uint8_t* rope_next = rope_src(t2);
-          const float* scale_next = scale_src(t2);
+          const float* scale_next = FMT == 0 ? scale_src(t2) : nullptr;
           int t3 = i + 2 + FL_Y_PF < n ? i + 2 + FL_Y_PF : n - 1;   // L2-prefetch target (inside the page-id window)
           t3 = t3 < win_base + 64 ? t3 : win_base + 63;
           const uint8_t* pf_next = g_k_nope + page_of(t3) * (long long)(kPage * kDN) + w4 * 8192 + lane * 128;
@@ -573,6 +684,12 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           FL_T(0);   // barrier
           const int tok0w = (tile_b + i) * kPage + 32 * W;
           const bool need_mask = (tile_b + i) * kPage + kPage > L_min;
+          if constexpr (FMT == 1)
+            qk_step1(l_run, lq_run, m_w, lc, lane, qn, qr8, qs, rr, rope_next,
+                     smem + kOffRing + (i & 3) * kSlotBytes + W * (32 * kDN),
+                     smem + kOffPbuf + (i & 1) * kPbufPerParity + (rt * 2 + W) * (64 * 16),
+                     reinterpret_cast<float*>(smem + kOffRef + (i & 1) * kRefPerParity) + (rt * 2 + W) * 32, tok0w, L_row, need_mask);
+          else
           qk_step(l_run, lq_run, m_w, lc, lane, qn, qr_lds, qs, rr, rn.ks, rope_next, scale_next, pf_next, pf_acc,
                   smem + kOffRing + (i & 3) * kSlotBytes + W * (32 * kDN), scratch + (i & 1) * 96, scratch + ((i + 1) & 1) * 96,
                   smem + kOffPbuf + (i & 1) * kPbufPerParity + (rt * 2 + W) * (64 * 16),
@@ -636,7 +753,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const int vrow = 4 * lh + tok_in8;
     lc.vb0 = vrow * kDN + ((((gi << 2)) ^ (vrow & 15)) << 4) + (s16 & 1) * 8;
     // latent DMA piece k of this wave: token row T = (w4*8 + k)*2 + lh, chunk li stored from source chunk li ^ (T&15)
-    lc.dn_row = (unsigned)((w4 * kPiecesPerWave * 2 + lh) * kDN);
+    lc.dn_row = (unsigned)((w4 * kPiecesPerWave * 2 + lh) * (FMT == 1 ? kDN + kDR : kDN));
     lc.dn_x = (unsigned)((li ^ lh) << 4);
   }
   int* msync = reinterpret_cast<int*>(smem + kOffMerge);
@@ -647,12 +764,12 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const int split_base = g_num_splits[req];
     const bool is_split = (g_num_splits[req + 1] - split_base) > 1;
     auto ring = [&](int t) { return smem + kOffRing + (t & 3) * kSlotBytes; };
-    auto src_of = [&](int t) { return g_k_nope + page_of(t) * (long long)(kPage * kDN); };
+    auto src_of = [&](int t) { return g_k_nope + page_of(t) * (long long)(kPage * (FMT == 1 ? kDN + kDR : kDN)); };
     auto issue_page = [&](int t) {
       const uint8_t* sn = src_of(t);
       uint8_t* dst = ring(t) + w4 * (kPiecesPerWave * 1024);
 #pragma unroll
-      for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s(sn, dn_off(lc, k), dst + k * 1024);
+      for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s(sn, dn_off<FMT>(lc, k), dst + k * 1024);
     };
     const float* lm = reinterpret_cast<const float*>(smem + kOffLm) + rt * 192;
 
@@ -692,13 +809,13 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const uint8_t* sn = HAS_DMA ? src_of(i + 2) : nullptr;                                                             \
     uint8_t* dst = ring(i + 2) + w4 * (kPiecesPerWave * 1024);                                                         \
     if (HAS_PREV) {                                                                                                    \
-      pv_step<HAS_DMA>(o, m_o, redo, lc, lane, ring(i - 1) + W * 256,                                                  \
+      pv_step<HAS_DMA, FMT>(o, m_o, redo, lc, lane, ring(i - 1) + W * 256,                                                  \
                        smem + kOffPbuf + ((i - 1) & 1) * kPbufPerParity + rt * (2 * 64 * 16),                          \
                        reinterpret_cast<const float*>(smem + kOffRef + ((i - 1) & 1) * kRefPerParity) + rt * 64, sn,   \
                        dst FL_T_ARGS);                                                                                 \
     } else {                                                                                                           \
       if (HAS_DMA) {                                                                                                   \
-        _Pragma("unroll") for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s(sn, dn_off(lc, k), dst + k * 1024);      \
+        _Pragma("unroll") for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s(sn, dn_off<FMT>(lc, k), dst + k * 1024);      \
       }                                                                                                                \
       if (FL_Y_MID_BARRIER) __builtin_amdgcn_s_barrier(); /* M_i */                                                    \
     }                                                                                                                  \
@@ -735,7 +852,8 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const float fA = __builtin_amdgcn_exp2f(mA - m_o), fB = __builtin_amdgcn_exp2f(mB - m_o);   // <= 2^kMaxUp
     const float l = lm[li] * fA + lm[96 + li] * fB;
     const float lq = lm[32 + li] * fA + lm[96 + 32 + li] * fB;
-    const float inv = lq > 0.f ? 1.f / lq : 0.f;
+    // (FMT 1: V = fp8 x descale_k, one device scalar for the whole cache)
+    const float inv = (lq > 0.f ? 1.f / lq : 0.f) * (FMT == 1 ? (p.descale_k ? *p.descale_k : 1.f) : 1.f);
     const float lse_nat = l > 0.f ? (__builtin_amdgcn_logf(l) + m_o - kPShift) * 0.6931471805599453f : -INFINITY;
     // split-KV partials are normalised by lq, so they are COMBINED with lq-based weights; the exact LSE travels along
     const float lseq_nat = lq > 0.f ? (__builtin_amdgcn_logf(lq) + m_o - kPShift) * 0.6931471805599453f : -INFINITY;
@@ -860,7 +978,12 @@ int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipSt
   // row-parallel merge kernel is the better tool
   p.merge_in_kernel = (p.row_groups <= 6 && (merge_env == 0 || (merge_env < 0 && p.bs >= p.num_parts))) ? 1 : 0;
   const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(512);
-  mla_decode_y_kernel<<<grid, block, 0, stream>>>(
+  if (a->kv_format == FL_KV_FP8_576)
+    mla_decode_y_kernel<1><<<grid, block, 0, stream>>>(
+        p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, const_cast<int32_t*>(a->tile_scheduler_metadata), a->num_splits,
+        (const uint8_t*)a->k_nope, (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
+  else
+  mla_decode_y_kernel<0><<<grid, block, 0, stream>>>(
       p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, const_cast<int32_t*>(a->tile_scheduler_metadata), a->num_splits,
       (const uint8_t*)a->k_nope, (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
   FL_CHECK_LAUNCH("mla_decode_y_kernel");
