@@ -511,7 +511,10 @@ def make_fp8_576_case(lens, H, s_q, seed):
 
 
 @pytest.mark.parametrize("lens,H,s_q,dq,dk", [([128], 16, 1, 1.0, 1.0), ([1, 63, 65, 300], 128, 1, 1.0, 1.0),
-                                               ([70, 4, 200], 16, 4, 0.5, 2.0), ([3000], 64, 1, 1.0, 1.0)])
+                                               ([70, 4, 200], 16, 4, 0.5, 2.0), ([3000], 64, 1, 1.0, 1.0),
+                                               # the role-specialised kernel's FMT = 1 instantiation: split requests, non-unit
+                                               # descales, three row groups
+                                               ([2500, 700, 64, 1300], 128, 1, 0.25, 3.0), ([500, 129], 96, 2, 1.0, 0.5)])
 def test_flash_mla_with_kvcache_fp8(fm, lens, H, s_q, dq, dk):
     q, kc, bt, seq, pages = make_fp8_576_case(lens, H, s_q, seed=H + s_q)
     meta, ns = fm.get_mla_metadata(seq.to(dev()), s_q * H, 1)
@@ -523,12 +526,18 @@ def test_flash_mla_with_kvcache_fp8(fm, lens, H, s_q, dq, dk):
     torch.cuda.synchronize()
     ref, rlse = mla_ref.mla_decode_with_kvcache(q, kc.view(pages, 64, 1, 576), bt, seq, 512, SCALE, True, dq, dk)
     check(o.cpu(), lse.cpu(), ref, rlse, f"fp8_576 {lens}")
-    # bit-level statement of the kernel: same arithmetic with constant scales and fp8 rope
+    # bit-level statement of the kernel: same arithmetic with constant scales and fp8 rope.  The mapping for more than 32
+    # query rows (mla_decode_fp8_y.hip, FMT = 1) keeps descale_k OUT of P' (scores carry dq*dk, the output is multiplied by
+    # dk in the epilogue); the mapping for <= 32 rows folds log2(dk) into P' like the per-token format
     bsz = len(lens)
+    import os
+    y_map = s_q * H > 32 and os.environ.get("FLUENT_MLA_Y") != "0"
     emu, _ = mla_ref.mla_decode_fp8_per_token_emulated(
-        q[..., :512].contiguous(), torch.full((bsz, s_q, H, 1), dq), q[..., 512:].float(),
-        kc[..., :512].contiguous().view(pages, 64, 1, 512), torch.full((pages, 64, 1, 1), dk),
+        q[..., :512].contiguous(), torch.full((bsz, s_q, H, 1), dq * dk if y_map else dq), q[..., 512:].float(),
+        kc[..., :512].contiguous().view(pages, 64, 1, 512), torch.full((pages, 64, 1, 1), 1.0 if y_map else dk),
         kc[..., 512:].contiguous().view(torch.float8_e4m3fn).float().view(pages, 64, 1, 64), bt, seq, SCALE, True)
+    if y_map:
+        emu = emu * dk
     e = (o.cpu().double() - emu).abs()
     assert float(e.mean() / emu.abs().mean().clamp_min(1e-30)) < 3e-3
 
