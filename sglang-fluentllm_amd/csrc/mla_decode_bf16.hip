@@ -5,6 +5,10 @@
 //   s[r,t] = (q[r,:576] · k[t,:576]) * softmax_scale,  o[r,:] = sum_t softmax_t(s[r,:]) * k[t,:512]
 // with q, k, P in bf16 and fp32 accumulation (v_mfma_f32_32x32x16_bf16).  This is the coverage kernel of the non-FP8
 // KV dtype — same C-ABI, scheduler metadata and split-KV combine as the FP8 kernels; tuned far less (north_star is FP8).
+// Measured limits (round 2): 669 us at bs=128, seq=4096, H=128 (12 % of 8 TB/s; 37 % at H=16).  A tile costs ~5,200 cycles for
+// ~600 cycles of MFMA: every wave repeats the whole softmax of the tile (4x redundant) behind an LDS exchange of the partial
+// S^T and two barriers.  Two 32-row tiles per workgroup sharing the operand reads (tried: 744 us) do not help — the per-tile
+// cost doubles with the rows; the role-specialised structure of mla_decode_fp8_y.hip is what this kernel would need.
 //
 // Mapping (layouts probed in probes/probe_bf16.hip):
 //   * workgroup = 4 waves = one 32-row group of one request part; tile = 32 tokens (half a page, 36 KiB of bf16).
