@@ -258,3 +258,30 @@ def test_oneshot_two_processes_on_one_gpu_hipipc():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "oneshot_two_procs.py"), "2"], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("parity OK") == 2, r.stdout[-2000:]
+
+
+def test_fusion_entry_points_fall_back_to_the_collective_route_beyond_the_oneshot_capacity(monkeypatch):
+    """a token count above the one-shot workspace's capacity (here 16) silently takes the RCCL route (world 1: no exchange)
+    with identical results; nothing raises"""
+    import flashinfer.comm as comm
+    monkeypatch.setenv("FLUENT_ONESHOT", "1")
+    H = 2048
+    handles, wsp = comm.trtllm_create_ipc_workspace_for_all_reduce_fusion(0, 1, 16, H)
+    assert handles[0].oneshot is not None and handles[0].oneshot.max_tokens == 16
+    g = torch.Generator().manual_seed(9)
+    gamma = torch.rand(H, generator=g).to(torch.bfloat16).to(DEV)
+    outs = []
+    for T in (16, 17, 300):
+        x = torch.randn(T, H, generator=g).to(torch.bfloat16).to(DEV)
+        res = torch.randn(T, H, generator=g).to(torch.bfloat16).to(DEV)
+        r, n = torch.empty_like(x), torch.empty_like(x)
+        comm.trtllm_allreduce_fusion(allreduce_in=x, world_size=1, world_rank=0, token_num=T, hidden_dim=H, workspace_ptrs=wsp,
+                                     pattern_code=comm.AllReduceFusionPattern.kARResidualRMSNorm, residual_in=res, residual_out=r,
+                                     norm_out=n, rms_gamma=gamma, rms_eps=1e-6)
+        torch.cuda.synchronize()
+        x32 = x.float() + res.float()
+        assert torch.equal(r, x32.to(torch.bfloat16))
+        y = (x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16) * gamma
+        assert float((n.float() - y.float()).abs().max()) <= 2 ** -6 * float(y.float().abs().max())   # one bf16 ulp of slack
+    handles[0].oneshot.check()
+    comm.trtllm_destroy_ipc_workspace_for_all_reduce_fusion(handles)

@@ -115,3 +115,27 @@ def test_rope_absorb_prepare_call_output_q_rope_and_fused_set_kv(T, H, loc_dtype
         arg.k_scale = 0.5
         flashinfer.apply_rope_with_cos_sin_cache_inplace(pos, q_in[..., 128:], K[..., 512:], 64, cache, is_neox=False,
                                                          fused_set_kv_buffer_arg=arg)
+
+
+def test_fused_set_kv_skips_negative_cache_locations():
+    """a negative cache_loc entry (padded request) rotates k_pe in place but writes no cache row"""
+    import flashinfer
+
+    g = torch.Generator().manual_seed(2)
+    T, H, slots = 6, 8, 20
+    q = torch.randn(T, H, 192, generator=g).to(torch.bfloat16).to(DEV)
+    latent = torch.randn(T, 576, generator=g).to(torch.bfloat16).to(DEV)
+    cache = torch.randn(100, 64, generator=g).to(DEV)
+    pos = torch.randint(0, 100, (T,), generator=g).to(DEV)
+    loc = torch.tensor([3, -1, 7, 0, -1, 19], dtype=torch.int64, device=DEV)
+    kv = torch.full((slots, 1, 576), 5.0, dtype=torch.bfloat16, device=DEV)
+    K = latent.clone().unsqueeze(1)
+    arg = flashinfer.FusedSetKVBufferArg(value=K[..., :512], k_buffer=kv[..., 512:].view(slots, -1), v_buffer=kv[..., :512].view(slots, -1),
+                                         k_scale=None, v_scale=None, cache_loc=loc)
+    flashinfer.apply_rope_with_cos_sin_cache_inplace(pos, q[..., 128:], K[..., 512:], 64, cache, is_neox=False, fused_set_kv_buffer_arg=arg)
+    torch.cuda.synchronize()
+    written = [3, 7, 0, 19]
+    src = [0, 2, 3, 5]
+    assert torch.equal(kv[written, 0], K[src, 0])
+    untouched = [i for i in range(slots) if i not in written]
+    assert bool((kv[untouched] == 5.0).all())
