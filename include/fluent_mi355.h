@@ -85,8 +85,11 @@ typedef struct FlMlaDecodeArgs {
   const int32_t* block_table; /* i32 [bs, block_table_stride] page ids (bit-exact, allocator.py:60-102) */
   int64_t block_table_stride;
   const int32_t* cache_seqlens; /* i32 [bs] */
-  const int32_t* tile_scheduler_metadata; /* from fl_mla_get_metadata; columns 5..7 of every row are scratch counters of the
-                                            * in-kernel split merge: zero on entry, zero again when the launch has finished */
+  int32_t* tile_scheduler_metadata; /* from fl_mla_get_metadata.  NOT const: columns 5..7 of every row are scratch counters of
+                                      * the in-kernel split merge — zero on entry, WRITTEN by fl_mla_decode, zero again when
+                                      * the launch has finished.  Ordering rule: launches that share one metadata tensor must
+                                      * be ordered on ONE stream (or by events); two concurrent launches on the same tensor
+                                      * would mix their arrival counts.  Give concurrent streams their own copy. */
   const int32_t* num_splits;
   /* outputs */
   void* out;                /* bf16 [bs,s_q,h_q,d_nope] */

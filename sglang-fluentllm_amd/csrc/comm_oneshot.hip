@@ -11,8 +11,12 @@
 //     RMSNorm -> optional 1x128 e4m3 quantisation                      (row work: norm_row.h, same code as norm_fused.hip)
 // Protocol, layout, and why two buffer parities suffice: comm_protocol.h.  The workspace is allocated uncached
 // (fine-grained): a peer's stores must become visible to a kernel that is already running here.
-// A wait that exceeds its time budget sets the sticky error word and the kernel ends (fl_comm_check reports it): a lost
-// peer must not hang the GPU.
+// A wait that exceeds its time budget (default 120 s: far beyond any plausible rank skew — GC pause, module load, weight
+// reload; fl_comm_set_timeout changes it) is FATAL for the communicator, never silent: the kernel writes NaN into every
+// output row it owns, sets the sticky error word in the workspace AND in a host-mapped word, and does not advance the
+// epoch.  Later launches — also replays of a captured graph — see the error word first, poison their outputs at once and
+// touch no peer; the next host-side launch call (and fl_comm_check) returns an error, which the Python route raises.
+// A lost peer therefore cannot hang the GPU, and a late one cannot make a rank consume rows of the wrong epoch.
 #include <string.h>
 
 #include <chrono>
@@ -38,6 +42,8 @@ struct FlComm {
   bool opened[kMaxWorld];
   bool connected;
   double timeout_s;
+  unsigned* host_err;       // host-mapped word (hipHostMalloc): != 0 once any kernel of this communicator has timed out
+  unsigned* host_err_dev;   // its device address
 };
 
 __device__ __forceinline__ void store_flag(uint8_t* ws, const long long idx, const unsigned e) {
@@ -55,6 +61,20 @@ __device__ __forceinline__ bool wait_flag(uint8_t* ws, const long long idx, cons
   return true;
 }
 
+// the outputs of row `row` as NaN (bf16 0x7FC0, e4m3fn 0x7F, f32 NaN scales): what a failed exchange leaves behind
+__device__ __forceinline__ void poison_row(const long long row, const int H, uint16_t* residual_out, uint16_t* norm_out,
+                                           uint8_t* quant_out, float* scale_out, const long long ss_t, const long long ss_g) {
+  for (int col = threadIdx.x * 8; col < H; col += 256 * 8) {
+    const uint4 nan16 = make_uint4(0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u);
+    if (residual_out != nullptr) *reinterpret_cast<uint4*>(residual_out + row * H + col) = nan16;
+    if (norm_out != nullptr) *reinterpret_cast<uint4*>(norm_out + row * H + col) = nan16;
+    if (quant_out != nullptr) {
+      *reinterpret_cast<uint2*>(quant_out + row * H + col) = make_uint2(0x7F7F7F7Fu, 0x7F7F7F7Fu);
+      if ((col & 127) == 0) scale_out[row * ss_t + (col >> 7) * ss_g] = __uint_as_float(0x7FC00000u);
+    }
+  }
+}
+
 // grid = T + 1 workgroups: block t < T owns token row t, block T keeps the ranks in step (the sync row)
 template <bool kRS>
 __global__ __launch_bounds__(256) void oneshot_kernel(const Peers peers, const int rank, const FlCommLayout L,
@@ -64,16 +84,18 @@ __global__ __launch_bounds__(256) void oneshot_kernel(const Peers peers, const i
                                                       uint16_t* __restrict__ residual_out, uint16_t* __restrict__ norm_out,
                                                       uint8_t* __restrict__ quant_out, float* __restrict__ scale_out,
                                                       const long long ss_t, const long long ss_g,
-                                                      const unsigned long long budget) {
+                                                      const unsigned long long budget, unsigned* __restrict__ host_err) {
   __shared__ float wsum[4];
   __shared__ unsigned s_epoch;
   __shared__ int s_fail;
+  __shared__ unsigned s_dead;
   uint8_t* me = peers.ws[rank];
   FlCommState* st = reinterpret_cast<FlCommState*>(me);
   const int tid = threadIdx.x;
   const int W = L.world;
   if (tid == 0) {
     s_epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_dead = __hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     s_fail = 0;
   }
   __syncthreads();
@@ -82,6 +104,14 @@ __global__ __launch_bounds__(256) void oneshot_kernel(const Peers peers, const i
   const long long t = blockIdx.x;
   bool consume = false;
   long long row_l = 0;
+  if (s_dead != 0u) {   // an earlier launch of this communicator timed out: no push, no wait, NaN outputs, epoch untouched
+    if (t < T) {
+      const int owner = kRS ? fl_comm_owner(T, W, t) : 0;
+      if (!kRS || owner == rank)
+        poison_row(kRS ? t - fl_comm_slice_lo(T, W, owner) : t, H, residual_out, norm_out, quant_out, scale_out, ss_t, ss_g);
+    }
+    return;
+  }
   if (t < T) {
     // ---- push: this rank's row t into the inbox of its destination(s) ----
     uint4 r[fl_norm::kRowChunks];
@@ -117,13 +147,18 @@ __global__ __launch_bounds__(256) void oneshot_kernel(const Peers peers, const i
   }
   __syncthreads();
   if (s_fail) {
-    if (tid == 0) __hip_atomic_store(&st->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) {
+      __hip_atomic_store(&st->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (consume) poison_row(row_l, H, residual_out, norm_out, quant_out, scale_out, ss_t, ss_g);
   } else if (consume) {
     const uint16_t* xrow = reinterpret_cast<const uint16_t*>(me + fl_comm_inbox_offset(L)) + fl_comm_inbox_row(L, par, 0, row_l);
     fl_norm::add_rmsnorm_row(xrow, W, L.max_tokens * (long long)L.hidden, add_in, residual_in, gamma, eps, row_l, H, residual_out,
                              norm_out, quant_out, scale_out, ss_t, ss_g, wsum);
   }
-  // ---- the last workgroup out advances the epoch (the next launch on this stream starts after this one has ended) ----
+  // ---- the last workgroup out advances the epoch (the next launch on this stream starts after this one has ended) —
+  //      unless any workgroup of this launch timed out: the ranks are out of step then, and the epoch stays where it is ----
   __syncthreads();
   if (tid == 0) {
     __threadfence();
@@ -131,7 +166,8 @@ __global__ __launch_bounds__(256) void oneshot_kernel(const Peers peers, const i
     if (old == gridDim.x - 1) {
       st->arrive = 0;
       __threadfence();
-      __hip_atomic_store(&st->epoch, e + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u)
+        __hip_atomic_store(&st->epoch, e + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -140,6 +176,11 @@ int launch(FlComm* c, bool rs, const void* in, int64_t T, int H, const void* add
            float eps, void* residual_out, void* norm_out, void* quant_out, float* scale_out, int64_t ss_t, int64_t ss_g,
            fl_stream_t stream) {
   FL_CHECK_ARG(c != nullptr && c->connected, "one-shot comm: not connected (fl_comm_connect)");
+  if (__atomic_load_n(c->host_err, __ATOMIC_RELAXED) != 0u) {   // (a plain host read: no device synchronisation)
+    fl_set_error("one-shot comm: an earlier launch timed out waiting for a peer (rank %d of %d); the communicator is dead, "
+                 "its outputs since then are NaN — re-create it", c->rank, c->world);
+    return FL_ERR_LAUNCH;
+  }
   FL_CHECK_ARG(T >= 0 && T <= c->L.max_tokens * (rs ? c->world : 1) && T <= kMaxOneShotTokens,
                "one-shot comm: T=%lld exceeds the workspace (max_tokens %lld)", (long long)T, c->L.max_tokens);
   FL_CHECK_ARG(H > 0 && H % 8 == 0 && H <= c->L.hidden && H <= fl_norm::kMaxChunks * 512, "one-shot comm: H=%d (workspace hidden %d)", H,
@@ -157,11 +198,11 @@ int launch(FlComm* c, bool rs, const void* in, int64_t T, int H, const void* add
   if (rs)
     oneshot_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(
         peers, c->rank, c->L, (const uint16_t*)in, T, H, (const uint16_t*)add_in, (const uint16_t*)residual_in, (const uint16_t*)gamma,
-        eps, (uint16_t*)residual_out, (uint16_t*)norm_out, (uint8_t*)quant_out, scale_out, ss_t, ss_g, budget);
+        eps, (uint16_t*)residual_out, (uint16_t*)norm_out, (uint8_t*)quant_out, scale_out, ss_t, ss_g, budget, c->host_err_dev);
   else
     oneshot_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(
         peers, c->rank, c->L, (const uint16_t*)in, T, H, (const uint16_t*)add_in, (const uint16_t*)residual_in, (const uint16_t*)gamma,
-        eps, (uint16_t*)residual_out, (uint16_t*)norm_out, (uint8_t*)quant_out, scale_out, ss_t, ss_g, budget);
+        eps, (uint16_t*)residual_out, (uint16_t*)norm_out, (uint8_t*)quant_out, scale_out, ss_t, ss_g, budget, c->host_err_dev);
   FL_CHECK_LAUNCH("oneshot_kernel");
   return FL_OK;
 }
@@ -184,8 +225,23 @@ extern "C" int fl_comm_create(int rank, int world, int64_t max_tokens, int hidde
   c->world = world;
   c->L = FlCommLayout{world, max_tokens, hidden};
   c->connected = false;
-  c->timeout_s = 2.0;
+  c->timeout_s = 120.0;
+  c->host_err = c->host_err_dev = nullptr;
   for (int p = 0; p < kMaxWorld; ++p) { c->peer[p] = nullptr; c->opened[p] = false; }
+  {
+    void* hp = nullptr;
+    void* dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hp) (void)hipHostFree(hp);
+      delete c;
+      fl_set_error("fl_comm_create: cannot allocate the host-mapped error word");
+      return FL_ERR_LAUNCH;
+    }
+    memset(hp, 0, 64);
+    c->host_err = (unsigned*)hp;
+    c->host_err_dev = (unsigned*)dp;
+  }
   const size_t bytes = (size_t)fl_comm_workspace_bytes(c->L);
   void* ptr = nullptr;
   hipError_t err = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocUncached);
@@ -194,6 +250,7 @@ extern "C" int fl_comm_create(int rank, int world, int64_t max_tokens, int hidde
     err = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocFinegrained);
   }
   if (err != hipSuccess) {
+    (void)hipHostFree(c->host_err);
     delete c;
     fl_set_error("fl_comm_create: cannot allocate %zu bytes of fine-grained device memory: %s", bytes, hipGetErrorString(err));
     return FL_ERR_LAUNCH;
@@ -204,6 +261,7 @@ extern "C" int fl_comm_create(int rank, int world, int64_t max_tokens, int hidde
   if (hipMemset(ptr, 0, bytes) != hipSuccess || hipMemcpy(ptr, &st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess ||
       hipDeviceSynchronize() != hipSuccess) {
     (void)hipFree(ptr);
+    (void)hipHostFree(c->host_err);
     delete c;
     fl_set_error("fl_comm_create: cannot initialise the workspace");
     return FL_ERR_LAUNCH;
@@ -250,7 +308,7 @@ extern "C" int fl_comm_connect(void* comm, const void* handles /* world x 64 byt
 
 extern "C" int fl_comm_set_timeout(void* comm, double seconds) {
   FlComm* c = (FlComm*)comm;
-  FL_CHECK_ARG(c && seconds > 0 && seconds <= 600, "fl_comm_set_timeout: bad arguments");
+  FL_CHECK_ARG(c && seconds > 0 && seconds <= 3600, "fl_comm_set_timeout: bad arguments");
   c->timeout_s = seconds;
   return FL_OK;
 }
@@ -291,6 +349,7 @@ extern "C" int fl_comm_destroy(void* comm) {
   for (int p = 0; p < c->world; ++p)
     if (c->opened[p]) (void)hipIpcCloseMemHandle(c->peer[p]);
   (void)hipFree(c->local);
+  if (c->host_err) (void)hipHostFree(c->host_err);
   delete c;
   return FL_OK;
 }

@@ -2,7 +2,9 @@
 // the host emulation of the same protocol (fl_comm_host_exchange: what the CPU-side two-process protocol test drives).
 //
 // Every rank owns ONE workspace that its peers map (hipIpc) and WRITE into:
-//   [state 256 B][flags u32 [2 parity][world + 1][max_tokens]][inbox bf16 [2 parity][world][max_tokens][hidden]]
+//   [state 256 B][flags u32 [2 parity][world + 1][max(max_tokens, world)]][inbox bf16 [2 parity][world][max_tokens][hidden]]
+// (a flag row has max(max_tokens, world) entries: the sync row is indexed by source RANK, so with max_tokens < world a
+//  row of max_tokens entries would alias the neighbouring rows)
 // An operation with epoch e (1, 2, 3, ... — the same on every rank: all ranks issue the same sequence) uses parity e & 1:
 //   push : source rank s writes its row for destination row r into the DESTINATION's inbox[parity][s][r], fences
 //          (system scope), then stores e into the destination's flags[parity][s][r];
@@ -19,7 +21,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FL_HD __host__ __device__ inline
 #else
 #define FL_HD static inline
@@ -28,7 +30,9 @@
 struct FlCommState {       // first 256 bytes of a workspace
   uint32_t epoch;          // epoch of the NEXT operation (starts at 1)
   uint32_t arrive;         // workgroups of the running kernel that are done
-  uint32_t error;          // != 0: a wait timed out (sticky; fl_comm_check reports it)
+  uint32_t error;          // != 0: a wait timed out.  STICKY and fatal for this communicator: the failing launch poisons its
+                           // outputs with NaN, does not advance the epoch, and every later launch poisons its outputs at
+                           // once without touching a peer (the ranks are out of step; re-create the communicator)
   uint32_t pad[61];
 };
 
@@ -39,11 +43,12 @@ struct FlCommLayout {
 };
 
 FL_HD long long fl_comm_flags_offset() { return 256; }
+FL_HD long long fl_comm_flag_cols(const FlCommLayout L) { return L.max_tokens > L.world ? L.max_tokens : (long long)L.world; }
 FL_HD long long fl_comm_flag_index(const FlCommLayout L, int parity, int src /*0..world; world = the sync row*/, long long row) {
-  return ((long long)parity * (L.world + 1) + src) * L.max_tokens + row;
+  return ((long long)parity * (L.world + 1) + src) * fl_comm_flag_cols(L) + row;
 }
 FL_HD long long fl_comm_inbox_offset(const FlCommLayout L) {
-  const long long flags = 2ll * (L.world + 1) * L.max_tokens * 4;
+  const long long flags = 2ll * (L.world + 1) * fl_comm_flag_cols(L) * 4;
   return 256 + ((flags + 255) / 256) * 256;
 }
 FL_HD long long fl_comm_inbox_row(const FlCommLayout L, int parity, int src, long long row) {   // in bf16 elements from the inbox base

@@ -912,14 +912,19 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     //      LDS whether this workgroup is the last.  The last one reads the other parts' partials (agent-scope loads of
     //      agent-scope stores: no cache-wide fence) and writes the final rows, 16 rows per PV wave (combine_rows16). ----
     if (is_split && p.merge_in_kernel) {
-      // this wave's partial stores are pushed past the XCD's L2 before anything downstream can count the fragment as done:
-      // a RELEASE fence at agent scope (L2 write-back + wait; it invalidates nothing, the page streams of the other
-      // workgroups keep their lines).  A bare s_waitcnt vmcnt(0) was not enough: the bit-identity test of the ragged
-      // full-size case caught a merge that had read a partial row before it left the writer's L2.
+      // Hand-off form (MI355X guide, "handoff-flag": write-through payload -> drained vmcnt -> counter -> sc1 loads):
+      //   * every partial row / LSE pair above was stored with the agent-scope policy (sc1 = write-through past this
+      //     XCD's non-coherent L2: st_agent_16B / st_agent_f32), and the merging part reads them back with sc1 loads
+      //     (combine_rows16: agent-scope relaxed atomic loads), which are served by the memory side, never by a stale
+      //     L1 / L2 line — so no cache-wide write-back or invalidate is needed on either side;
+      //   * the wave drains its own stores here (inline asm: a wait hipcc cannot drop) BEFORE it is counted as arrived
+      //     in LDS; the fourth arriver bumps the request's agent-scope counter only after all four waves have drained.
+      // (Round 2 shipped this code with an agent RELEASE fence behind an #ifdef that no build defined, next to a comment
+      //  saying the wait alone had not been enough — that observation predates the write-through stores.  The form that
+      //  has actually been validated, in round 2 and again in round 3, is this fence-less one: tools/determinism_ragged.py,
+      //  profiles/r03_determinism_ragged_inkernel_merge.txt.  A per-fragment buffer_wbl2 would also be correct but
+      //  writes back the XCD's whole L2 under the other workgroups' page streams.)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef FL_Y_MERGE_RELEASE_FENCE
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
       int verdict = 0;
       if (lane == 0) {
         const int old = __hip_atomic_fetch_add(msync, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);

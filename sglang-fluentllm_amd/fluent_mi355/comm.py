@@ -218,13 +218,30 @@ def _gather_rows_uneven(rows, counts, rank, total, group, out=None):
     padded[:counts[rank]].copy_(rows)
     buf = torch.empty((W * cmax,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
     dist.all_gather_into_tensor(buf, padded, group=group)
-    key = (tuple(counts), str(rows.device))
+    torch.index_select(buf, 0, _compaction_index(counts, rows.device), out=out)
+    return out
+
+
+def _compaction_index(counts, device):
+    """row t of the compacted [total] layout -> its row in the padded [W * cmax] gather.  Built ON the device from arange
+    arithmetic (no pageable host-to-device copy: safe to meet a new `counts` for the first time inside hipGraph capture,
+    and no host sync outside it) and cached per (counts, device).  get_num_tokens_per_rank: the first `rem` ranks own
+    `base + 1` rows, the rest `base`."""
+    key = (tuple(counts), str(device))
     idx = _compact_idx.get(key)
     if idx is None:
-        idx = torch.tensor([r * cmax + i for r in range(W) for i in range(counts[r])], dtype=torch.int64, device=rows.device)
+        W, total, cmax = len(counts), sum(counts), max(counts)
+        base, rem = total // W, total % W
+        assert list(counts) == [base + (1 if r < rem else 0) for r in range(W)], "counts do not follow get_num_tokens_per_rank"
+        t = torch.arange(total, dtype=torch.int64, device=device)
+        big = rem * (base + 1)
+        r_hi = t // (base + 1)                                   # owner if t < big
+        r_lo = rem + (t - big) // max(base, 1)                   # owner otherwise
+        owner = torch.where(t < big, r_hi, r_lo)
+        start = owner * base + torch.clamp(owner, max=rem)       # first row of the owner's slice
+        idx = owner * cmax + (t - start)
         _compact_idx[key] = idx
-    torch.index_select(buf, 0, idx, out=out)
-    return out
+    return idx
 
 
 def _gather_pieces(x, ws):
@@ -257,10 +274,13 @@ def trtllm_allreduce_fusion(allreduce_in, world_size, world_rank, token_num, hid
         # one launch: push over xGMI, per-row flags, fused epilogue (csrc/comm_oneshot.hip)
         x = allreduce_in.contiguous()
         if only_sum:
-            osc.allreduce_fused(x, residual_out=allreduce_out)
-        else:
+            if osc.accepts(x, False, residual_out=allreduce_out):
+                osc.allreduce_fused(x, residual_out=allreduce_out)
+                return
+        elif osc.accepts(x, False, None, residual_in, rms_gamma, residual_out, norm_out, quant_out, scale_out):
             osc.allreduce_fused(x, residual_in, rms_gamma, rms_eps, residual_out, norm_out, quant_out, scale_out)
-        return
+            return
+        # (tensors the one-shot kernel's raw-pointer contract does not cover — other dtypes, strided views: RCCL route)
     counts = get_num_tokens_per_rank(W, T)
     lo = sum(counts[:world_rank]) if W > 1 else 0
     hi = lo + (counts[world_rank] if W > 1 else T)
@@ -300,10 +320,12 @@ def trtllm_reducescatter_fusion(reducescatter_in, world_size, world_rank, token_
             and (only_sum or reducescatter_out is None)):
         x = reducescatter_in.contiguous()
         if only_sum:
-            osc.reducescatter_fused(x, residual_out=reducescatter_out)
-        else:
+            if osc.accepts(x, True, residual_out=reducescatter_out):
+                osc.reducescatter_fused(x, residual_out=reducescatter_out)
+                return
+        elif osc.accepts(x, True, add_in, residual_in, rms_gamma, residual_out, norm_out, quant_out, scale_out):
             osc.reducescatter_fused(x, add_in, residual_in, rms_gamma, rms_eps, residual_out, norm_out, quant_out, scale_out)
-        return
+            return
     counts = get_num_tokens_per_rank(W, T)
     mine = counts[world_rank] if W > 1 else T
     if W == 1:

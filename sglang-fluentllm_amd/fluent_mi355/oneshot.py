@@ -9,6 +9,7 @@ call.  `fluent_mi355.comm` routes to it for token counts up to `max_tokens` (env
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -44,6 +45,8 @@ class OneShotComm:
         either all ranks end up connected or ALL raise RuntimeError (nobody is left on a different route)."""
         self.rank, self.world, self.hidden = int(rank), int(world), int(hidden)
         self.max_tokens = min(int(max_tokens), MAX_ONESHOT_TOKENS)
+        if timeout_s is None and os.environ.get("FLUENT_ONESHOT_TIMEOUT_S"):
+            timeout_s = float(os.environ["FLUENT_ONESHOT_TIMEOUT_S"])   # default (C side): 120 s
         self._h = None
         if exchange is None:
             def exchange(obj):
@@ -86,8 +89,46 @@ class OneShotComm:
     def _strides(scale_out):
         return (0, 0) if scale_out is None else (scale_out.stride(0), scale_out.stride(1))
 
+    def slice_rows(self, tokens, reduce_scatter):
+        """rows of the per-rank tensors of an operation over `tokens` rows (get_num_tokens_per_rank for a reduce-scatter)"""
+        if not reduce_scatter:
+            return tokens
+        return tokens // self.world + (1 if self.rank < tokens % self.world else 0)
+
+    def accepts(self, x, reduce_scatter=False, add_in=None, residual_in=None, gamma=None, residual_out=None, norm_out=None,
+                quant_out=None, scale_out=None):
+        """What the kernel assumes about the tensors it is handed raw pointers of (the same contract HipNormOps.add_rmsnorm
+        asserts on the RCCL route): bf16, contiguous, on this device, [rows, H] with rows = this rank's slice for the
+        per-rank tensors; quant_out 1-byte [rows, H]; scale_out f32 2-D covering [rows, H/128].  False -> take the RCCL
+        route (comm.py) instead of misreading memory."""
+        if x.dim() != 2 or x.dtype != torch.bfloat16 or not x.is_cuda or not x.is_contiguous():
+            return False
+        T, H = x.shape
+        rows = self.slice_rows(T, reduce_scatter)
+        for t in (add_in, residual_in, residual_out, norm_out):
+            if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous() or t.device != x.device
+                                  or t.dim() != 2 or t.shape[0] < rows or t.shape[1] != H):
+                return False
+        if gamma is not None and (gamma.dtype != torch.bfloat16 or not gamma.is_contiguous() or gamma.device != x.device
+                                  or gamma.numel() != H):
+            return False
+        if quant_out is not None:
+            if (quant_out.element_size() != 1 or not quant_out.is_contiguous() or quant_out.device != x.device
+                    or quant_out.dim() != 2 or quant_out.shape[0] < rows or quant_out.shape[1] != H or H % 128):
+                return False
+            if (scale_out is None or scale_out.dtype != torch.float32 or scale_out.device != x.device or scale_out.dim() != 2
+                    or scale_out.shape[0] < rows or scale_out.shape[1] < H // 128):
+                return False
+        return True
+
+    def _require(self, ok, what):
+        if not ok:
+            raise ValueError(f"one-shot comm {what}: tensors must be bf16, contiguous, on one device, [rows, H] with this "
+                             "rank's row count (fp8 quant_out [rows, H], f32 scale_out [rows, >= H/128]); use the RCCL route")
+
     def allreduce_fused(self, x, residual_in=None, gamma=None, eps=1e-6, residual_out=None, norm_out=None, quant_out=None,
                         scale_out=None):
+        self._require(self.accepts(x, False, None, residual_in, gamma, residual_out, norm_out, quant_out, scale_out), "allreduce_fused")
         T, H = x.shape
         st, sg = self._strides(scale_out)
         check(lib.fl_allreduce_fused(self._h, x.data_ptr(), T, H, _p(residual_in), _p(gamma), float(eps), _p(residual_out),
@@ -95,6 +136,8 @@ class OneShotComm:
 
     def reducescatter_fused(self, x, add_in=None, residual_in=None, gamma=None, eps=1e-6, residual_out=None, norm_out=None,
                             quant_out=None, scale_out=None):
+        self._require(self.accepts(x, True, add_in, residual_in, gamma, residual_out, norm_out, quant_out, scale_out),
+                      "reducescatter_fused")
         T, H = x.shape
         st, sg = self._strides(scale_out)
         check(lib.fl_reducescatter_fused(self._h, x.data_ptr(), T, H, _p(add_in), _p(residual_in), _p(gamma), float(eps),

@@ -260,6 +260,18 @@ def test_oneshot_two_processes_on_one_gpu_hipipc():
     assert r.stdout.count("parity OK") == 2, r.stdout[-2000:]
 
 
+def test_oneshot_lost_peer_poisons_outputs_and_raises():
+    """A peer that never issues an operation: the waiting rank's launch ends after its time budget with NaN in every output
+    row (never partial sums), the epoch is not advanced, the next launch call and check() raise, and the late rank fails
+    the same way instead of consuming rows of the wrong epoch."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "oneshot_two_procs.py"), "2", "lostpeer"], capture_output=True,
+                       text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("lost-peer handling OK") == 2, r.stdout[-2000:]
+
+
 def test_fusion_entry_points_fall_back_to_the_collective_route_beyond_the_oneshot_capacity(monkeypatch):
     """a token count above the one-shot workspace's capacity (here 16) silently takes the RCCL route (world 1: no exchange)
     with identical results; nothing raises"""

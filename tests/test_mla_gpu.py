@@ -127,6 +127,8 @@ def run_decode(fm, c, H, s_q=1, causal=True, emulate=True):
     return o.cpu(), lse.cpu(), ref, rlse, ns.cpu()
 
 
+K1_REL_MAE_BOUND = 3.2e-2   # = 1.15 x 2.74e-2, the maximum over 11 shapes x 200 seeds (profiles/r03_mla_seed_sweep.json)
+
 MEASURED = []   # (tag, rel-MAE, max-abs, max|ref|, max LSE error): written out by test_zz_write_measured_errors
 
 
@@ -145,14 +147,16 @@ def _check(o, lse, ref, rlse, tag):
     _fin = torch.isfinite(rlse)
     MEASURED.append({"case": str(tag), "rel_mae": rel, "max_abs": float(err.max()), "max_ref": float(ref.abs().max()),
                      "lse_err": float((lse.double()[_fin] - rlse[_fin]).abs().max()) if bool(_fin.any()) else 0.0})
-    # stated FP8 tolerance vs dequantise-then-exact attention: rel-MAE < 2.7e-2 = 1.16 x the worst MEASURED case (2.33e-2, h40_padrows,
-    # over the 32 cases of this file incl. the full-size ones: profiles/r02_mla_parity_measured.json; 1.25 x was the plan at 2.15e-2), max-abs < 1e-1 on
-    # N(0,1)-scaled data (|o| <= ~4; for larger outputs the absolute bound scales with the data).  SURVEY section 8c's 2e-2
-    # is what exact P would give; here P is re-quantised to e4m3 for the MX PV MFMA (3 mantissa bits, rms relative rounding
-    # 2^-4/sqrt(3) = 3.6 % per weight): on i.i.d. V rows signal and rounding noise both scale as 1/sqrt(N_eff), so rel-MAE
-    # sits at 1.7-2.2e-2 for every length (the CPU emulation of the kernel's arithmetic reproduces it to three digits).
+    # stated FP8 tolerance vs dequantise-then-exact attention: rel-MAE < K1_REL_MAE_BOUND = 1.15 x the WORST case of a seed
+    # sweep (tools/seed_sweep_mla.py: every CASES shape x 200 seeds -> profiles/r03_mla_seed_sweep.json; cfg1 — seq 128,
+    # 16 heads, the smallest sample — has the widest spread: 1.4e-2 .. 2.74e-2, mean 2.1e-2), max-abs < 1e-1 on N(0,1)-scaled
+    # data (|o| <= ~4; for larger outputs the absolute bound scales with the data).  SURVEY section 8c's 2e-2 is what an
+    # exact P would give; here — as in the reference's own flashmla-fp8, whose PV GEMM is fp8 x fp8 — P is re-quantised to
+    # e4m3 for the MX PV MFMA (3 mantissa bits, rms relative rounding 2^-4/sqrt(3) = 3.6 % per weight): on i.i.d. V rows
+    # signal and rounding noise both scale as 1/sqrt(N_eff), so the mean sits at 1.2-2.2e-2 for every length (the CPU
+    # emulation of the kernel's arithmetic reproduces the distribution: same tool with --emulated).
     # The bit-level statement of the kernel is checked to 3e-3 in run_decode.
-    assert rel < 2.7e-2, (tag, rel)
+    assert rel < K1_REL_MAE_BOUND, (tag, rel)
     # max-abs: 1e-1 on N(0,1) data for ordinary lengths; 2-3-token sequences are the worst case of fp8 weights: the weight
     # ratio moves by <= 2*2^-4*w1*w2 <= 3.1e-2, times |v1-v2| <= 2 max|v|  ->  bound 5e-2 * max|o| covers it
     assert float(err.max()) < max(1e-1, 5e-2 * float(ref.abs().max())), (tag, float(err.max()))
@@ -178,9 +182,13 @@ CASES = [
 ]
 
 
+CASE_SEEDS = {c[0]: 100 + i for i, c in enumerate(CASES)}
+
+
 @pytest.mark.parametrize("name,lens,H,s_q", CASES, ids=[c[0] for c in CASES])
 def test_decode_parity_vs_oracle(fm, name, lens, H, s_q):
-    c = make_paged_case(lens, H, s_q=s_q, seed=hash(name) % 1000)
+    # fixed seed per case (NOT hash(name): Python string hashes are randomised per process, so every run drew new inputs)
+    c = make_paged_case(lens, H, s_q=s_q, seed=CASE_SEEDS[name])
     o, lse, ref, rlse, ns = run_decode(fm, c, H, s_q)
     check(o, lse, ref, rlse, name)
 

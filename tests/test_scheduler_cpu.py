@@ -46,3 +46,20 @@ def test_small_batch_splits_long_sequence():
     assert ns[1] == 32  # one long request is spread over many CUs: max(32, pages/8) parts (256 pages -> 32 x 8 here)
     meta, ns = _coverage([65536], 256)
     assert ns[1] == 128
+
+
+def test_seed_sweep_covers_the_cases():
+    """tools/seed_sweep_mla.py (the source of the K1 tolerance) sweeps exactly the shapes of test_mla_gpu.CASES"""
+    import ast
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def literal(path, name):
+        tree = ast.parse(open(path).read())
+        for node in tree.body:
+            if isinstance(node, ast.Assign) and any(getattr(t, "id", None) == name for t in node.targets):
+                return ast.literal_eval(node.value)
+        raise AssertionError(name)
+
+    assert literal(os.path.join(root, "tools", "seed_sweep_mla.py"), "SHAPES") == literal(
+        os.path.join(root, "tests", "test_mla_gpu.py"), "CASES")

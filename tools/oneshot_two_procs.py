@@ -52,8 +52,63 @@ def worker(rank, world, port, T, H, iters):
         raise SystemExit(1)
 
 
+def lost_peer_worker(rank, world, port, T, H):
+    """rank 1 skips one operation: rank 0's wait runs out of its (here 1 s) budget.  Required behaviour: the
+    failing launch leaves NaN in every output row, never partial sums; the epoch does not advance; the next launch call
+    raises; a rank whose peer is dead fails the same way one operation later — nothing hangs, nothing is silently wrong."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from fluent_mi355.oneshot import OneShotComm
+    c = OneShotComm(rank, world, 64, H, timeout_s=1.0)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(T, H, generator=g).to(torch.bfloat16).to(dev)
+    res = torch.randn(T, H, generator=g).to(torch.bfloat16).to(dev)
+    gamma = torch.rand(H, generator=g).to(torch.bfloat16).to(dev)
+    o_res, o_norm = torch.zeros(T, H, dtype=torch.bfloat16, device=dev), torch.zeros(T, H, dtype=torch.bfloat16, device=dev)
+    c.allreduce_fused(x, res, gamma, 1e-6, o_res, o_norm)          # both ranks: fine
+    torch.cuda.synchronize(); dist.barrier()
+    ok = bool(torch.isfinite(o_norm.float()).all())
+    if rank == 0:
+        o_res.zero_(); o_norm.zero_()
+        c.allreduce_fused(x, res, gamma, 1e-6, o_res, o_norm)      # the peer never issues this one
+        torch.cuda.synchronize()
+        ok &= bool(torch.isnan(o_res.float()).all()) and bool(torch.isnan(o_norm.float()).all())
+        raised = False
+        try:
+            c.allreduce_fused(x, res, gamma, 1e-6, o_res, o_norm)  # dead communicator: the launch call itself reports it
+        except RuntimeError as ex:
+            raised = "timed out" in str(ex)
+        ok &= raised
+        try:
+            c.check(); ok = False
+        except RuntimeError:
+            pass
+    dist.barrier()
+    if rank != 0:
+        # the late rank: operation 2 still completes — rank 0 pushed its (valid) rows and flags for it before it gave up —
+        # but operation 3 finds nobody (rank 0 is dead at epoch 2 and pushes nothing any more): NaN, not a hang
+        c.allreduce_fused(x, res, gamma, 1e-6, o_res, o_norm)
+        torch.cuda.synchronize()
+        ok &= bool(torch.isfinite(o_norm.float()).all())
+        o_res.zero_(); o_norm.zero_()
+        c.allreduce_fused(x, res, gamma, 1e-6, o_res, o_norm)
+        torch.cuda.synchronize()
+        ok &= bool(torch.isnan(o_norm.float()).all())
+    print(f"rank {rank}/{world}: lost-peer handling {'OK' if ok else 'WRONG'}", flush=True)
+    dist.barrier()
+    c.close()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
 if __name__ == "__main__":
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    mp.spawn(worker, args=(world, port, 48, 7168, 5), nprocs=world, join=True)
+    if len(sys.argv) > 2 and sys.argv[2] == "lostpeer":
+        mp.spawn(lost_peer_worker, args=(2, port, 16, 2048), nprocs=2, join=True)
+    else:
+        mp.spawn(worker, args=(world, port, 48, 7168, 5), nprocs=world, join=True)
