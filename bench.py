@@ -537,7 +537,7 @@ def main_cfg4(a, dev, world, rank, dist):
                                    f"seq=8192) + EP{world} MoE ({info['experts_per_rank']} experts/rank, top-8), all-gather + "
                                    "reduce-scatter + EP dispatch/combine over RCCL inside the step",
                        "layers_per_step": layers, "parallelism": f"tp{world}/ep{world}", "hipgraph": graph is not None,
-                       "hipgraph_refused": why, **info},
+                       "hipgraph_refused": why, **{k: v for k, v in info.items() if not k.startswith("_")}},
             "roofline": None, "cpu_baseline": None}))
     if dist is not None:
         dist.destroy_process_group()

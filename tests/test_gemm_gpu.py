@@ -186,6 +186,47 @@ def test_grouped_offset_e256_top8_routing_vs_oracle(T, zipf, N, K):
     assert bool((out[M:] == 7.0).all())
 
 
+@pytest.mark.parametrize("T,zipf", [(128, 0.0), (4096, 0.0), (4096, 1.2)])
+def test_cfg3_full_size_sampled_experts_vs_oracle(T, zipf):
+    """BASELINE config 3 at FULL size — E = 256 experts x w13 [4096, 7168] (7.5 GB of fp8 weights) and w2 [7168, 2048], top-8
+    routing of T tokens (decode: 4 rows per expert; 4096: 128 rows per expert -> the 128- and, with the Zipf load, the
+    256-row tiles) — the shape bench.py times, which the small-N/K E=256 tests and the E<=32 full-N/K tests only bracket.
+    Weights and activations are generated on the device; six sampled experts (first, last, the 64-group boundaries of the tile
+    lookup, the most and the least loaded non-empty one) are copied back and recomputed by oracle.gemm_ref."""
+    import deep_gemm
+
+    E, K1, N1, N2 = 256, 7168, 4096, 7168
+    counts = _route_counts(T, E, 8, zipf, seed=31 + T + int(zipf * 10))
+    ex = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32)
+    M = int(ex[-1])
+    g = torch.Generator(device=DEV).manual_seed(T + 1)
+
+    def dev_fp8(*shape):   # uniform random e4m3 bytes without the NaN patterns
+        b = torch.randint(0, 255, shape, device=DEV, generator=g, dtype=torch.int16)
+        return torch.where((b & 0x7F) == 0x7F, b - 1, b).to(torch.uint8).view(torch.float8_e4m3fn)
+
+    nonempty = [e for e in range(E) if counts[e] > 0]
+    picks = sorted({nonempty[0], nonempty[-1], min(nonempty, key=lambda e: abs(e - 63.5)), min(nonempty, key=lambda e: abs(e - 128)),
+                    max(nonempty, key=lambda e: counts[e]), min(nonempty, key=lambda e: counts[e])})
+    mp = (M + E * 31) // 32 * 32 + 32
+    for (N, K) in ((N1, K1), (N2, N1 // 2)):          # w13: [4096, 7168]; w2: [7168, 2048]
+        x = (torch.randn(M, K, device=DEV, generator=g) / 3).to(torch.bfloat16)
+        xq_ref, xs_ref = gemm_ref.per_token_group_quant_fp8(x.cpu(), 128)
+        W = dev_fp8(E, N, K)
+        Ws = torch.rand(E, N // 128, K // 128, device=DEV, generator=g) * 1e-2
+        xs_dev = torch.zeros((K // 128, mp), dtype=torch.float32, device=DEV).permute(-1, -2)
+        xs_dev[:M] = xs_ref.to(DEV)
+        out = torch.full((M + 2, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset((xq_ref.to(DEV), xs_dev[:M]), (W, Ws), out[:M], ex.to(DEV))
+        torch.cuda.synchronize()
+        assert bool((out[M:] == 7.0).all()) and bool(torch.isfinite(out[:M].float()).all())
+        for e in picks:
+            lo, hi = int(ex[e]), int(ex[e + 1])
+            ref = gemm_ref.block_fp8_matmul(xq_ref[lo:hi], W[e].cpu(), xs_ref[lo:hi], Ws[e].cpu())
+            assert rel_mae(out[lo:hi].cpu(), ref) < 1e-3, (N, K, e, hi - lo)
+        del W, Ws, out, x
+
+
 def test_grouped_contiguous_and_masked_vs_oracle():
     import deep_gemm
 

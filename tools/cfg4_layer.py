@@ -91,7 +91,7 @@ def build(dev, world, rank, group, layers, seq=SEQ, bs=BS, seed=0):
                                      pattern_code=comm.AllGatherFusionPattern.kAllGather)
         q8, s8 = per_token_group_quant_fp8(B["full"], column_major_scales=True)
         deep_gemm.gemm_fp8_fp8_bf16_nt((q8, s8), w["qkv_a"], B["qkv"])
-        bench.layer_call(fm, wl, l, meta, ns)                                          # K5 + K4 + K1
+        B["mla_o"], _ = bench.layer_call(fm, wl, l, meta, ns)                          # K5 + K4 + K1
         oq, os_ = per_token_group_quant_fp8(attn_o, column_major_scales=True)
         deep_gemm.gemm_fp8_fp8_bf16_nt((oq, os_), w["o"], B["o"])
         # C6: reduce-scatter of the o_proj partial sums + residual + post-attention norm on the rank's slice
@@ -101,6 +101,7 @@ def build(dev, world, rank, group, layers, seq=SEQ, bs=BS, seed=0):
                                          residual_out=B["res"], norm_out=B["norm2"], rms_gamma=w["gamma2"], rms_eps=1e-6)
         logits = torch.matmul(B["norm2"], w["router"].t()).float()                     # router GEMM: a plain library GEMM
         tw, ti = flashinfer.moe_fused_gate(logits, w["bias"], N_GROUP, TOPK_GROUP, TOPK, routed_scaling_factor=2.5)
+        B["logits"], B["topk_w"], B["topk_ids"] = logits, tw, ti
         a2a.dispatch(out_exclusive_sum=B["ex"], out_expert_x=B["xrows"], dp_x=B["norm2"], indices=ti, num_global_tokens=bs)
         flashinfer.quantization.quant_1x128(B["xrows"], B["xq"], B["xs"], B["ex"], el, (rows + 3) // 4 * 4, mp, HID)
         deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset((B["xq"], B["xs"]), w["w13"], B["gate_up"], B["ex"], use_pdl=True)
@@ -123,4 +124,6 @@ def build(dev, world, rank, group, layers, seq=SEQ, bs=BS, seed=0):
     info = dict(bs=bs, seq=seq, heads_per_rank=h, experts_per_rank=el, tokens_per_rank=t_loc, routed_row_bound=rows,
                 ep_slab_rows_per_peer=a2a.cap, kv_bytes_per_layer=kv_bytes, weight_bytes_per_layer=w_bytes,
                 xgmi_send_bytes_per_layer=xgmi)
+    # everything a checker needs to recompute the layer from its inputs (tests/test_cfg4_gpu.py); not used by the bench
+    info["_state"] = dict(W=W, B=B, wl=wl, hid_loc=hid_loc, attn_o=attn_o, meta=meta, ns=ns, res_in=B["res"].clone())
     return step, info
