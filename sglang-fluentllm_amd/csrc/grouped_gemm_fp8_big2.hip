@@ -1,0 +1,368 @@
+// G1-G3 for MANY rows per group, round 3: the 256 x 256 tile of grouped_gemm_fp8_big.hip rebuilt around what round 2
+// measured: the old k loop was a 2-stage ring of whole 128-byte k blocks with
+// `vmcnt(0)` + barrier at the top of every k block — a prefetch distance of ONE k block, all eight waves in the same
+// wait -> barrier -> compute phase, the matrix pipe idle through every wait (4,244 cycles per k block against 2,048 of
+// MFMA per SIMD).  Same math, call sites and data formats (deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_*).
+//
+//   * RING: 4 slots of HALF k blocks (64 bytes of k = one MX MFMA deep): [W 256 rows x 64 B | A 256 rows x 64 B] =
+//     32 KiB per slot, refilled THREE half steps ahead with counted `vmcnt` (never 0 in the loop): a piece has 2.5-3
+//     half steps (~3,000 cycles) to land instead of one k block minus the issue time.
+//   * NO PARTIAL TILES: a half step cannot keep 8 transient 32 x 32 partials (128 registers), so the per-128-k scale
+//     s = As[m,kb] * Ws[e,nb,kb] is applied INSIDE the accumulate chain: s = 2^e * f with f in [1,2); the power of two
+//     goes into the MX block scale of the token-side operand (E8M0 = the fp32 exponent field, exact), and the accumulator
+//     is kept in units of the current mantissa: acc' <- acc' * (f_prev / f) once per k block (the same 16 VALU ops per
+//     tile the old `acc += part * s` promotion cost), out = acc' * f_last.  fp32 rounding per step instead of none:
+//     1e-7 relative per k block against the 1e-3 tolerance of the reference's block-fp8 tests.
+//   * TWO WAVE GROUPS IN ANTI-PHASE: waves 0-3 (token half 0) and 4-7 (token half 1) share the four SIMDs pairwise and
+//     run half a step apart, separated by workgroup barriers: while one wave of a SIMD issues its 8 MFMAs (segment M),
+//     its partner issues LDS-DMA, reads operands and rescales (segment L).  Intervals:
+//         X:  L0 | M0 | L1 | M1 | ...            (barrier between all segments; Y executes one barrier more up front,
+//         Y:     | L0 | M0 | L1 | M1 | ...        X one more at the end)
+//   * XCD-aware tile order: the 32 workgroups of an XCD in one round take 32 CONSECUTIVE tiles (n fastest): the tiles of
+//     one 512-row expert (2 x 16 tiles of w13) share their W and A panels through ONE L2.
+#include "grouped_gemm_shared.h"
+
+using namespace fl_gemm;
+
+namespace {
+
+#ifdef FL_GEMM2_TIMING
+__device__ unsigned long long* g_g2dbg = nullptr;
+#define GT(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); gt[i] += t__ - gl; gl = t__; } while (0)
+#else
+#define GT(i) do { } while (0)
+#endif
+
+constexpr int BMB = 256;                 // token rows per workgroup
+constexpr int BNB = 256;                 // weight rows per workgroup
+constexpr int BKH = 64;                  // half k block (bytes per row per ring slot)
+constexpr int kWHalf = BNB * BKH;        // 16 KiB
+constexpr int kAHalf = BMB * BKH;        // 16 KiB
+constexpr int kSlot = kWHalf + kAHalf;   // 32 KiB
+constexpr int kSlots = 4;
+constexpr int kAsSlot = 8 * 64 * 4;      // 2 KiB: wave w stores the scales of tokens 32w + (lane & 31) at floats [64w, 64w + 64)
+constexpr int kSmem2 = kSlots * kSlot + 2 * kAsSlot;   // 135,168 B
+
+// MFMAs as inline asm (volatile: they keep their order relative to each other and to the LDS-DMA asm).  Scale operands: byte 0
+// of a VGPR, E8M0; src0 (weights) always 2^0, src1 (tokens: one column per lane) the power-of-two part of the lane's
+// block scale.  `s_nop 1`: the operands may have been written by the VALU just before (hipcc pads nothing inside asm).
+__device__ __forceinline__ void mfma_zero(v16f& acc, const v8i a, const v8i b, const int sb) {
+  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0]"
+               : "=&v"(acc)
+               : "v"(a), "v"(b), "v"(kUnit), "v"(sb));
+}
+__device__ __forceinline__ void mfma_acc(v16f& acc, const v8i a, const v8i b, const int sb) {
+  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
+               : "+v"(acc)
+               : "v"(a), "v"(b), "v"(kUnit), "v"(sb));
+}
+
+#define G2_BARRIER()                          \
+  do {                                        \
+    __builtin_amdgcn_sched_barrier(0);        \
+    __builtin_amdgcn_s_barrier();             \
+    asm volatile("" ::: "memory");            \
+    __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+
+__global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const GemmParams p, const uint8_t* __restrict__ gA,
+                                                                      const float* __restrict__ gAs,
+                                                                      const uint8_t* __restrict__ gW,
+                                                                      const float* __restrict__ gWs,
+                                                                      const int32_t* __restrict__ gmeta) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[kSmem2];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wn = wave & 3, wm = wave >> 2;
+
+  // ---- XCD-aware tile order (speed only): workgroup b runs on XCD b % 8; within a round of 256 workgroups XCD x takes
+  //      the logical tiles [32x, 32x + 32) of the round.  The last, partial round keeps the identity order. ----
+  const int n_tiles = p.n_tiles;
+  int lid = blockIdx.x;
+  {
+    const int total = gridDim.x, round = lid >> 8;
+    if ((round + 1) * 256 <= total) lid = (round << 8) + ((lid & 7) << 5) + ((lid & 255) >> 3);
+  }
+  const int nt = lid % n_tiles;
+  const int mt = lid / n_tiles;
+  int e = 0;
+  long long row0 = 0, row_end = 0;
+  if (!locate_tile<BMB>(p, gmeta, mt, e, row0, row_end)) return;
+  const int n0 = nt * BNB;
+  const int KB = p.K / BK;
+  const int NH = 2 * KB;
+
+  // ---- LDS-DMA sources.  A half-step stage = 32 pieces of 1 KiB (16 rows x 64 B): wave w issues W pieces 2w, 2w+1 and A
+  //      pieces 2w, 2w+1.  Lane i of a piece lands at +16 i: row i >> 2, chunk POSITION i & 3, which holds source chunk
+  //      (i & 3) ^ ((row >> 2) & 3) — the swizzle is on the source address, the LDS image is lane-linear (conflict-free
+  //      ds_read_b128 below: a 16-lane read group covers all 16 bank slots of 16 B) ----
+  const uint8_t* w_base = gW + (long long)e * p.N * p.K;
+  const uint8_t* a_base = gA + row0 * p.K;
+  const unsigned swz = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+  const unsigned n_last = (unsigned)p.N - 1u;                    // rows beyond N: clamped, results discarded
+  const unsigned m_last = (unsigned)(row_end - row0 - 1);        // rows beyond the group: clamped, never stored
+  unsigned voff_w0, voff_w1, voff_a0, voff_a1;
+  {
+    const unsigned r = (unsigned)(32 * wave + (lane >> 2));
+    unsigned n = (unsigned)n0 + r;
+    voff_w0 = __umul24(n < n_last ? n : n_last, (unsigned)p.K) + swz;
+    n += 16u;
+    voff_w1 = __umul24(n < n_last ? n : n_last, (unsigned)p.K) + swz;
+    voff_a0 = __umul24(r < m_last ? r : m_last, (unsigned)p.K) + swz;
+    voff_a1 = __umul24(r + 16u < m_last ? r + 16u : m_last, (unsigned)p.K) + swz;
+  }
+  const float* as_src;   // the block scales of token 32 wave + (lane & 31)
+  {
+    long long m = row0 + 32 * wave + li;
+    m = m < row_end ? m : row_end - 1;
+    as_src = p.mode == kMasked ? gAs + (long long)e * p.as_stride_g + (m - (long long)e * p.rows_per_group) * p.as_stride_m
+                               : gAs + m * p.as_stride_m;
+  }
+  auto uniform = [](const uint8_t* ptr) {   // (keeps the 64-bit base in an SGPR pair: the asm operand is "s")
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const uint8_t*>(((unsigned long long)hi << 32) | lo);
+  };
+  // Stage hs (may run past the last one: the source is clamped, the slot is idle by then — ONE body, constant vmcnt counts)
+  auto issue = [&](const int hs, const bool even) {
+    const int hc = hs < NH ? hs : NH - 1;
+    uint8_t* s = smem + (hs & (kSlots - 1)) * kSlot + (2 * wave) * 1024;
+    const uint8_t* wb = uniform(w_base + (long long)hc * BKH);
+    const uint8_t* ab = uniform(a_base + (long long)hc * BKH);
+    fl_dma16_s(wb, voff_w0, s);
+    fl_dma16_s(wb, voff_w1, s + 1024);
+    fl_dma16_s(ab, voff_a0, s + kWHalf);
+    fl_dma16_s(ab, voff_a1, s + kWHalf + 1024);
+    if (even) {   // the token scales of k block hs / 2 travel with its first half
+      const int kb = hs >> 1, kc = kb < KB ? kb : KB - 1;
+      fl_dma4(as_src + (long long)kc * p.as_stride_k, smem + kSlots * kSlot + (kb & 1) * kAsSlot + wave * 256);
+    }
+  };
+
+  // operand read offsets: row li of a 32-row block (64 B per row), the lane half's 32 k bytes = chunks 2 lh, 2 lh + 1
+  const int rb0 = li * BKH + ((((2 * lh) ^ ((li >> 2) & 3))) << 4);
+  const int rb1 = li * BKH + ((((2 * lh + 1) ^ ((li >> 2) & 3))) << 4);
+  auto ld8 = [&](const uint8_t* base) {
+    const v4i lo = *reinterpret_cast<const v4i*>(base + rb0);
+    const v4i hi = *reinterpret_cast<const v4i*>(base + rb1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  v16f acc[2][4];   // [weight-row block i][token block j]: D^T[32 weight rows, 32 tokens], one token per lane
+  float cmant[4];   // per token block j: the mantissa the accumulators of column j are currently in units of
+  int e8[4];        // E8M0 scale of the current k block (= the fp32 exponent field of As * Ws)
+  float ratio[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { cmant[j] = 1.f; e8[j] = kUnit; ratio[j] = 1.f; }
+
+  const float* wsrow = gWs + ((long long)e * ((p.N + BN - 1) / BN) + (n0 + 64 * wn) / BN) * KB;
+  v8i wa[2], tb[4];
+
+  // ---- segment L: refill, operand reads, (first half of a k block:) scales + rescale of token blocks 2, 3 ----
+  auto seg_load = [&](const int h, const bool even, const bool first_kb) {
+    issue(h + 3, !even);   // (h + 3 is even iff h is odd)
+    const uint8_t* sw = smem + (h & (kSlots - 1)) * kSlot + (64 * wn) * BKH;
+    const uint8_t* sa = smem + (h & (kSlots - 1)) * kSlot + kWHalf + (128 * wm) * BKH;
+    wa[0] = ld8(sw);
+    wa[1] = ld8(sw + 32 * BKH);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tb[j] = ld8(sa + j * (32 * BKH));
+    if (even) {
+      const int kb = h >> 1;
+      const float ws = wsrow[kb];
+      const float* sas = reinterpret_cast<const float*>(smem + kSlots * kSlot + (kb & 1) * kAsSlot) + 64 * (4 * wm) + li;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float s = sas[64 * j] * ws;
+        const unsigned bits = __float_as_uint(s);
+        const unsigned eb = (bits >> 23) & 0xffu;
+        // zero / denormal scale: 2^-127 x 1.0 (the term is below anything fp32 can add to the sum anyway)
+        const float f = eb != 0u ? __uint_as_float((bits & 0x807fffffu) | 0x3f800000u) : 1.f;
+        ratio[j] = cmant[j] * __builtin_amdgcn_rcpf(f);
+        cmant[j] = f;
+        e8[j] = (int)eb;
+      }
+      if (!first_kb) {
+        // the MFMAs of these tiles were the FIRST of the previous M segment (>= 4 MFMA times ago) — margin for the
+        // XDL-write -> VALU-read rule that hipcc cannot see through the asm
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][2]), "+v"(acc[1][2]), "+v"(acc[0][3]), "+v"(acc[1][3]));
+#pragma unroll
+        for (int j = 2; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= ratio[j];
+            asm volatile("" : "+v"(acc[i][j]));
+          }
+      }
+    }
+  };
+  // ---- segment M: 8 MFMAs, token blocks 2, 3 first; in the first half of a k block the rescale of blocks 0, 1 rides in
+  //      the shadow of those MFMAs ----
+  auto seg_mma = [&](const bool even, const bool first_kb) {
+    __builtin_amdgcn_s_setprio(1);
+    if (even && first_kb) {
+#pragma unroll
+      for (int j = 2; j < 6; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) mfma_zero(acc[i][j & 3], wa[i], tb[j & 3], e8[j & 3]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = 2 + (t >> 1), i = t & 1;
+        mfma_acc(acc[i][j], wa[i], tb[j], e8[j]);
+        if (even) {   // rescale tile t of the blocks 0, 1 (its last MFMA was issued a whole M + L segment ago)
+          const int jr = t >> 1, ir = t & 1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ir][jr][r] *= ratio[jr];
+          asm volatile("" : "+v"(acc[ir][jr]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = t >> 1, i = t & 1;
+        mfma_acc(acc[i][j], wa[i], tb[j], e8[j]);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+#ifdef FL_GEMM2_TIMING
+  unsigned long long gt[4] = {0, 0, 0, 0};
+  unsigned long long gl = __builtin_readcyclecounter();
+  const unsigned long long g0 = gl;
+#endif
+  // ---- prologue: three half-step stages in flight ----
+  issue(0, true);
+  issue(1, false);
+  issue(2, true);
+
+  // One k block of each group's stream.  `first` is a literal at both call sites (k block 0 is peeled off the loop: ONE body
+  // variant inside the loop — a run-time branch around the MFMAs makes hipcc copy the accumulators at the join).
+  auto kblock_x = [&](const int kb, const bool first) __attribute__((always_inline)) {
+    const int h = 2 * kb;
+    GT(1);
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // this wave's pieces of stage h (h + 1, h + 2 stay in flight)
+    GT(2);
+    G2_BARRIER();                                      // everyone's; slot h - 1 is free
+    GT(3);
+    seg_load(h, true, first);
+    GT(0);
+    G2_BARRIER();
+    GT(3);
+    seg_mma(true, first);
+    GT(1);
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    GT(2);
+    G2_BARRIER();
+    GT(3);
+    seg_load(h + 1, false, false);
+    GT(0);
+    G2_BARRIER();
+    GT(3);
+    seg_mma(false, false);
+  };
+  auto kblock_y = [&](const int kb, const bool first) __attribute__((always_inline)) {
+    const int h = 2 * kb;
+    GT(1);
+    G2_BARRIER();
+    GT(3);
+    seg_load(h, true, first);
+    // reads of slot h complete (group X refills it right after the next barrier) + this wave's pieces of stage h + 1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    GT(0);
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    GT(2);
+    G2_BARRIER();
+    GT(3);
+    seg_mma(true, first);
+    GT(1);
+    G2_BARRIER();
+    GT(3);
+    seg_load(h + 1, false, false);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    GT(0);
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    GT(2);
+    G2_BARRIER();
+    GT(3);
+    seg_mma(false, false);
+  };
+  if (wm == 0) {   // ---------------- group X ----------------
+    kblock_x(0, true);
+#pragma unroll 1
+    for (int kb = 1; kb < KB; ++kb) kblock_x(kb, false);
+    GT(1);
+    G2_BARRIER();   // (group Y's last M segment starts here)
+  } else {         // ---------------- group Y: the same stream, one segment later ----------------
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    G2_BARRIER();
+    kblock_y(0, true);
+#pragma unroll 1
+    for (int kb = 1; kb < KB; ++kb) kblock_y(kb, false);
+    GT(1);
+  }
+#ifdef FL_GEMM2_TIMING
+  if (g_g2dbg != nullptr && lane == 0 && blockIdx.x < 4096) {
+    unsigned long long* d = g_g2dbg + ((long long)blockIdx.x * 8 + wave) * 8;
+    d[0] = gt[0]; d[1] = gt[1]; d[2] = gt[2]; d[3] = gt[3]; d[4] = __builtin_readcyclecounter() - g0;
+  }
+#endif
+
+  // ---- epilogue: D^T[n, m] -> out[m, n] bf16; lane (m = token li of block j, half lh) holds n = 8g + 4lh + (0..3) ----
+  // (the last MFMAs are still in the pipe: a 16-pass XDL write needs 18 wait states before a VALU read)
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[0][1]), "+v"(acc[1][1]));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long m = row0 + 128 * wm + 32 * j + li;
+    const float cm = cmant[j];
+    if (m < row_end) {
+      uint16_t* orow = p.out + m * p.N;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + 64 * wn + 32 * i + 8 * g + 4 * lh;
+          if (n + 3 < p.N) {
+            *reinterpret_cast<uint2*>(orow + n) = make_uint2(fl_pack_bf16(acc[i][j][4 * g + 0] * cm, acc[i][j][4 * g + 1] * cm),
+                                                            fl_pack_bf16(acc[i][j][4 * g + 2] * cm, acc[i][j][4 * g + 3] * cm));
+          } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+              if (n + x < p.N) orow[n + x] = fl_f32_to_bf16(acc[i][j][4 * g + x] * cm);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+#ifdef FL_GEMM2_TIMING
+extern "C" int fl_gemm2_debug_set_buffer(unsigned long long* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_g2dbg), &dev_ptr, sizeof(dev_ptr));
+}
+#endif
+
+int fl_gemm_launch_big2(const GemmParams& p_in, const void* A, const float* As, const void* W, const float* Ws,
+                        const int32_t* group_meta, hipStream_t stream) {
+  GemmParams p = p_in;
+  long long m_tiles;
+  if (p.mode == kOffset) m_tiles = (p.M + BMB - 1) / BMB + p.E;
+  else if (p.mode == kMasked) m_tiles = (long long)p.E * ((p.rows_per_group + BMB - 1) / BMB);
+  else m_tiles = (p.M + BMB - 1) / BMB;
+  p.n_tiles = (p.N + BNB - 1) / BNB;
+  p.m_tiles_upper = (int)m_tiles;
+  const long long blocks = m_tiles * p.n_tiles;
+  FL_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fl_grouped_gemm_fp8: grid too large");
+  FL_CHECK_ARG(p.N < (1 << 24) && p.K < (1 << 24) && (long long)p.N * p.K < (1ll << 32),
+               "fl_grouped_gemm_fp8: N*K too large for the 256x256 tile");
+  grouped_gemm_fp8_big2_kernel<<<dim3((unsigned)blocks), dim3(512), 0, stream>>>(p, (const uint8_t*)A, As, (const uint8_t*)W, Ws,
+                                                                                group_meta);
+  FL_CHECK_LAUNCH("grouped_gemm_fp8_big2_kernel");
+  return FL_OK;
+}

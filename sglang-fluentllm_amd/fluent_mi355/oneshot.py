@@ -128,17 +128,19 @@ class OneShotComm:
 
     def allreduce_fused(self, x, residual_in=None, gamma=None, eps=1e-6, residual_out=None, norm_out=None, quant_out=None,
                         scale_out=None):
-        self._require(self.accepts(x, False, None, residual_in, gamma, residual_out, norm_out, quant_out, scale_out), "allreduce_fused")
         T, H = x.shape
+        if self.fits(T, H):   # (beyond the workspace the C side reports "exceeds the workspace")
+            self._require(self.accepts(x, False, None, residual_in, gamma, residual_out, norm_out, quant_out, scale_out), "allreduce_fused")
         st, sg = self._strides(scale_out)
         check(lib.fl_allreduce_fused(self._h, x.data_ptr(), T, H, _p(residual_in), _p(gamma), float(eps), _p(residual_out),
                                      _p(norm_out), _p(quant_out), _p(scale_out), st, sg, stream_ptr(x.device)), "fl_allreduce_fused")
 
     def reducescatter_fused(self, x, add_in=None, residual_in=None, gamma=None, eps=1e-6, residual_out=None, norm_out=None,
                             quant_out=None, scale_out=None):
-        self._require(self.accepts(x, True, add_in, residual_in, gamma, residual_out, norm_out, quant_out, scale_out),
-                      "reducescatter_fused")
         T, H = x.shape
+        if self.fits(T, H, reduce_scatter=True):
+            self._require(self.accepts(x, True, add_in, residual_in, gamma, residual_out, norm_out, quant_out, scale_out),
+                          "reducescatter_fused")
         st, sg = self._strides(scale_out)
         check(lib.fl_reducescatter_fused(self._h, x.data_ptr(), T, H, _p(add_in), _p(residual_in), _p(gamma), float(eps),
                                          _p(residual_out), _p(norm_out), _p(quant_out), _p(scale_out), st, sg, stream_ptr(x.device)),
