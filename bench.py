@@ -26,6 +26,7 @@ import torch  # noqa: E402
 LAYERS = 61
 BS, SEQ, H, S_Q = 128, 4096, 128, 1
 SCALE = 192 ** -0.5
+FUSED_QUANT = os.environ.get("FLUENT_BENCH_FUSED_QUANT", "1") != "0"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling ~6290 GB/s
 
 
@@ -65,8 +66,11 @@ def build_workload(dev, layers, bs, seq, h, seed):
 def layer_call(fm, wl, l, meta, ns):
     k_lora, k_scale, k_rope = wl["caches"][l]
     pages = wl["pages"]
-    fm.quantize_and_cache_k(wl["k_new"], k_lora, k_scale, k_rope, wl["out_loc"], 512)
-    qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
+    if FUSED_QUANT:   # K5 + K4 in one launch (flash_mla_fp8.quantize_q_and_cache_k): 2 launches per layer instead of 3
+        qn, qs, qr = fm.quantize_q_and_cache_k(wl["q"], wl["k_new"], k_lora, k_scale, k_rope, wl["out_loc"], 512)
+    else:             # the call sequence of the unmodified FlashMLABackend.forward_decode (flashmla_backend.py:188-206)
+        fm.quantize_and_cache_k(wl["k_new"], k_lora, k_scale, k_rope, wl["out_loc"], 512)
+        qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
     return fm.flash_mla_ckv_fp8_per_token(qn, qr, k_lora.view(pages, 64, 1, 512), k_rope.view(pages, 64, 1, 64), qs,
                                           k_scale.view(pages, 64, 1, 1), wl["block_table"], wl["seqlens"], 512, meta, ns,
                                           SCALE, True)
@@ -475,7 +479,9 @@ def main():
             "config": {"workload": "DeepSeek-V3 MLA decode, per-token fp8 KV, bs=128/GPU seq=4096 H=128 (TP=1), page=64, "
                                    "pages randomly permuted, K3 metadata once + 61 layers x (K5 store + K4 quant-q + K1 decode) per step",
                        "bs_per_gpu": BS, "seq_len": SEQ, "heads": H, "layers_per_step": layers,
-                       "parallelism": f"dp{world} (DP-attention, no data-path collective)", "hipgraph": graph is not None},
+                       "parallelism": f"dp{world} (DP-attention, no data-path collective)", "hipgraph": graph is not None,
+                       "launches_per_layer": 2 if FUSED_QUANT else 3,
+                       "quant_launch": "K5 + K4 fused (flash_mla_fp8.quantize_q_and_cache_k)" if FUSED_QUANT else "K5, K4 separate"},
             "roofline": roof, "gemm": gemm, "variants": variants, "cpu_baseline": cpu}))
     if dist is not None:
         dist.destroy_process_group()

@@ -57,6 +57,15 @@ int fl_mla_quant_store_k(const void* key, int64_t n, int d_nope, int d_rope, con
                          void* k_lora_cache, float* k_scale_cache, void* k_rope_cache, int64_t num_slots,
                          fl_stream_t stream);
 
+/* K5 + K4 in one launch: fl_mla_quant_store_k (rows of `key`, scattered at `indices`) and fl_mla_quant_q (rows of `q`, dense
+ * outputs) with the bytes of the two separate calls.  The reference issues them back to back in
+ * FlashMLABackend.forward_decode (flashmla_backend.py:188-206: set_kv_buffer -> memory_pool.py:864-871, then
+ * quantize_ckv_per_token_head); an integrator who wants one launch fewer per layer calls
+ * flash_mla_fp8.quantize_q_and_cache_k.  Either row count may be 0. */
+int fl_mla_quant_q_store_k(const void* key, int64_t n_k, const int32_t* indices, void* k_lora_cache, float* k_scale_cache,
+                           void* k_rope_cache, int64_t num_slots, const void* q, int64_t q_rows, int d_nope, int d_rope,
+                           void* q_nope, float* q_scale, void* q_rope, fl_stream_t stream);
+
 /* ---- K6: dequantize_ckv_fused_indexed (memory_pool.py:821-824; fallback :826-831) ---- */
 int fl_mla_dequant_gather(const void* k_lora_cache, const void* k_rope_cache, const float* k_scale_cache,
                           const int32_t* indices, int64_t n, int d_nope, int d_rope, int64_t num_slots,

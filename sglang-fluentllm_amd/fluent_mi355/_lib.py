@@ -43,11 +43,14 @@ def _load():
                                     _c_void_p, _c_void_p]
     lib_.fl_mla_quant_store_k.argtypes = [_c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _i32p, _c_void_p,
                                           _f32p, _c_void_p, ctypes.c_int64, _c_void_p]
+    lib_.fl_mla_quant_q_store_k.argtypes = [_c_void_p, ctypes.c_int64, _i32p, _c_void_p, _f32p, _c_void_p, ctypes.c_int64,
+                                            _c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_void_p, _f32p, _c_void_p,
+                                            _c_void_p]
     lib_.fl_mla_dequant_gather.argtypes = [_c_void_p, _c_void_p, _f32p, _i32p, ctypes.c_int64, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int64, _c_void_p, _c_void_p, _c_void_p]
     lib_.fl_mla_decode.argtypes = [ctypes.POINTER(FlMlaDecodeArgs), _c_void_p]
     for name in ("fl_device_cu_count", "fl_mla_num_parts", "fl_mla_get_metadata", "fl_mla_quant_q",
-                 "fl_mla_quant_store_k", "fl_mla_dequant_gather", "fl_mla_decode"):
+                 "fl_mla_quant_store_k", "fl_mla_quant_q_store_k", "fl_mla_dequant_gather", "fl_mla_decode"):
         getattr(lib_, name).restype = ctypes.c_int
     return lib_
 

@@ -83,6 +83,36 @@ def quantize_and_cache_k(key: torch.Tensor, k_lora_cache: torch.Tensor, k_lora_s
                                    num_slots, stream_ptr(key.device)), "fl_mla_quant_store_k")
 
 
+def quantize_q_and_cache_k(q: torch.Tensor, key: torch.Tensor, k_lora_cache: torch.Tensor, k_lora_scale_cache: torch.Tensor,
+                           k_rope_cache: torch.Tensor, indices: torch.Tensor, kv_lora_rank: int = 512):
+    """`quantize_and_cache_k(key, ...)` and `quantize_ckv_per_token_head(q, kv_lora_rank)` in ONE launch — the two calls
+    FlashMLABackend.forward_decode issues back to back (flashmla_backend.py:188-206).  Same bytes as the separate calls;
+    returns (q_nope, q_scale, q_rope).  Optional entry point for an integrator: the unmodified
+    backend keeps working with the two separate functions."""
+    for t, n in ((q, "q"), (key, "key"), (k_lora_cache, "k_lora_cache"), (k_lora_scale_cache, "k_lora_scale_cache"),
+                 (k_rope_cache, "k_rope_cache"), (indices, "indices")):
+        _cuda_contig(t, n)
+    _req(q.dtype == torch.bfloat16 and key.dtype == torch.bfloat16 and k_rope_cache.dtype == torch.bfloat16,
+         "q / key / rope cache must be bfloat16")
+    _req(k_lora_cache.dtype in _ONE_BYTE and k_lora_scale_cache.dtype == torch.float32, "bad cache dtypes")
+    _req(indices.dtype == torch.int32, "indices must be int32")
+    d = q.shape[-1]
+    _req(key.shape[-1] == d, "q / key row width mismatch")
+    d_rope = d - kv_lora_rank
+    n_k = key.numel() // d
+    _req(indices.numel() == n_k, "indices / key length mismatch")
+    rows = q.numel() // d
+    q_nope = torch.empty(q.shape[:-1] + (kv_lora_rank,), dtype=torch.float8_e4m3fn, device=q.device)
+    q_scale = torch.empty(q.shape[:-1] + (1,), dtype=torch.float32, device=q.device)
+    q_rope = torch.empty(q.shape[:-1] + (d_rope,), dtype=torch.bfloat16, device=q.device)
+    num_slots = k_lora_cache.numel() // kv_lora_rank
+    check(lib.fl_mla_quant_q_store_k(key.data_ptr(), n_k, indices.data_ptr(), k_lora_cache.data_ptr(),
+                                     k_lora_scale_cache.data_ptr(), k_rope_cache.data_ptr(), num_slots, q.data_ptr(), rows,
+                                     kv_lora_rank, d_rope, q_nope.data_ptr(), q_scale.data_ptr(), q_rope.data_ptr(),
+                                     stream_ptr(q.device)), "fl_mla_quant_q_store_k")
+    return q_nope, q_scale, q_rope
+
+
 def dequantize_ckv_fused_indexed(k_lora_fp8: torch.Tensor, k_rope: torch.Tensor, k_scale: torch.Tensor,
                                  indices: torch.Tensor):
     """-> (k_lora_deq bf16 [n,1,512], k_rope_deq bf16 [n,1,64]) gathered at `indices`."""

@@ -68,6 +68,33 @@ def test_quant_roundtrip_random_bit_exact_vs_oracle(fm):
     assert torch.equal(qr.cpu().view(torch.int16), rr.view(torch.int16))
 
 
+def test_fused_quant_q_and_cache_k_matches_the_two_separate_calls(fm):
+    """K5 + K4 in one launch (flash_mla_fp8.quantize_q_and_cache_k): bytes identical to quantize_and_cache_k followed by
+    quantize_ckv_per_token_head, at decode sizes (one row per wave) and above 8192 rows (two rows per wave, an odd number of
+    K rows so that a wave straddles the K / Q boundary); out-of-pool and negative cache locations are skipped as in K5."""
+    g = torch.Generator().manual_seed(33)
+    for bs, H, s_q in ((3, 16, 1), (128, 128, 1), (65, 128, 4)):
+        slots = 4096
+        key = (torch.randn(bs, 1, 576, generator=g) * torch.exp(torch.randn(bs, 1, 1, generator=g))).to(torch.bfloat16).to(dev())
+        q = torch.randn(bs, s_q, H, 576, generator=g).to(torch.bfloat16).to(dev())
+        loc = torch.randperm(slots, generator=g)[:bs].to(torch.int32)
+        loc[0] = -1
+        if bs > 2:
+            loc[2] = slots + 5
+        loc = loc.to(dev())
+        a = [torch.zeros(slots, 1, 512, dtype=torch.uint8, device=dev()), torch.zeros(slots, 1, 1, device=dev()),
+             torch.zeros(slots, 1, 64, dtype=torch.bfloat16, device=dev())]
+        b = [torch.zeros_like(t) for t in a]
+        fm.quantize_and_cache_k(key, a[0], a[1], a[2], loc, 512)
+        rn, rs, rr = fm.quantize_ckv_per_token_head(q, 512)
+        qn, qs, qr = fm.quantize_q_and_cache_k(q, key, b[0], b[1], b[2], loc, 512)
+        torch.cuda.synchronize()
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+        assert torch.equal(qn.view(torch.uint8), rn.view(torch.uint8)) and torch.equal(qs, rs)
+        assert torch.equal(qr.view(torch.int16), rr.view(torch.int16))
+
+
 # ---------------------------------------------------------------- K3: scheduler, bit-exact vs its Python statement
 @pytest.mark.parametrize("lens,rows", [([4096] * 128, 128), ([1] * 160, 16), ([0, 5, 200, 0, 9000], 128),
                                        ([16384], 64), ([63, 64, 65, 4095, 4097] * 7, 512)])
