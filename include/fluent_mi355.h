@@ -198,6 +198,14 @@ int fl_allreduce_fused(void* comm, const void* in, int64_t T, int H, const void*
 int fl_reducescatter_fused(void* comm, const void* in, int64_t T, int H, const void* add_in, const void* residual_in,
                            const void* gamma, float eps, void* residual_out, void* norm_out, void* quant_out, float* scale_out,
                            int64_t s_stride_t, int64_t s_stride_g, fl_stream_t stream);
+/* C7 / the all-gather half of C3 as one kernel (flashinfer.comm.trtllm_allgather_fusion, flashinfer_comm_fusion.py:613-638;
+ * eps.communication.TPDPConvertor.all_gather, layers/dp_attention.py:62-74): every rank holds `t_cur` =
+ * get_num_tokens_per_rank(world, T)[rank] rows `in [t_cur, D]`; out [T, D] receives all rows in rank order.  q_rank > 0: dual
+ * RMSNorm of every gathered row — cols [0, q_rank) -> x_norm_out [T, q_rank] (+ optional 1x128 fp8 quant_out / scale_out),
+ * cols [q_rank, q_rank + kv_rank) in place in `out`.  T <= 1024, ceil(T / world) <= max_tokens, D <= hidden. */
+int fl_allgather_fused(void* comm, const void* in, int64_t t_cur, int64_t T, int D, void* out, int q_rank, int kv_rank,
+                       const void* gamma_q, const void* gamma_kv, float eps_q, float eps_kv, void* x_norm_out, void* quant_out,
+                       float* scale_out, int64_t s_stride_t, int64_t s_stride_g, fl_stream_t stream);
 int fl_comm_check(void* comm /*synchronises; FL_ERR_LAUNCH if a flag wait ever timed out*/);
 int fl_comm_destroy(void* comm);
 /* The same protocol on plain host memory (shared-memory workspaces of several processes): drives the CPU-side protocol

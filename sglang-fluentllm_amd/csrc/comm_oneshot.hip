@@ -172,6 +172,97 @@ __global__ __launch_bounds__(256) void oneshot_kernel(const Peers peers, const i
   }
 }
 
+// C7 / C3 all-gather as ONE kernel (flashinfer.comm.trtllm_allgather_fusion, flashinfer_comm_fusion.py:516-640; the all-gather
+// half of eps.communication.TPDPConvertor, layers/dp_attention.py:62-74): token rows are split over the ranks as
+// get_num_tokens_per_rank does; workgroup t owns global row t — the rank that HOLDS the row pushes it into every rank's
+// inbox[parity][owner][row - lo(owner)] and raises that row's flag, every rank waits for the flag in its own inbox, copies
+// the row to out[t] and (C7) runs the dual RMSNorm on it (one wave; in place for the kv columns, q columns -> x_norm_out +
+// optional 1x128 fp8).  Same epochs / parities / sync row / failure handling as oneshot_kernel above.
+__global__ __launch_bounds__(256) void oneshot_ag_kernel(const Peers peers, const int rank, const FlCommLayout L,
+                                                         const uint16_t* __restrict__ in, const long long T, const int D,
+                                                         uint16_t* __restrict__ out, const int q_rank, const int kv_rank,
+                                                         const uint16_t* __restrict__ gamma_q, const uint16_t* __restrict__ gamma_kv,
+                                                         const float eps_q, const float eps_kv, uint16_t* __restrict__ x_norm_out,
+                                                         uint8_t* __restrict__ quant_out, float* __restrict__ scale_out,
+                                                         const long long ss_t, const long long ss_g, const unsigned long long budget,
+                                                         unsigned* __restrict__ host_err) {
+  __shared__ unsigned s_epoch;
+  __shared__ int s_fail;
+  __shared__ unsigned s_dead;
+  uint8_t* me = peers.ws[rank];
+  FlCommState* st = reinterpret_cast<FlCommState*>(me);
+  const int tid = threadIdx.x;
+  const int W = L.world;
+  if (tid == 0) {
+    s_epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_dead = __hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    s_fail = 0;
+  }
+  __syncthreads();
+  const unsigned e = s_epoch;
+  const int par = (int)(e & 1u);
+  const long long t = blockIdx.x;
+  auto poison = [&]() {   // NaN into everything this workgroup would have written
+    const uint4 nan16 = make_uint4(0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u);
+    for (int col = tid * 8; col < D; col += 256 * 8) *reinterpret_cast<uint4*>(out + t * D + col) = nan16;
+    if (q_rank > 0) poison_row(t, q_rank, nullptr, x_norm_out, quant_out, scale_out, ss_t, ss_g);
+  };
+  if (s_dead != 0u) {
+    if (t < T) poison();
+    return;
+  }
+  if (t < T) {
+    const int owner = fl_comm_owner(T, W, t);
+    const long long row_d = t - fl_comm_slice_lo(T, W, owner);
+    if (owner == rank) {   // this rank holds the row: push it to everyone (itself included)
+      for (int col = tid * 8; col < D; col += 256 * 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(in + row_d * D + col);
+        for (int p = 0; p < W; ++p)
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(peers.ws[p] + fl_comm_inbox_offset(L)) +
+                                    fl_comm_inbox_row(L, par, rank, row_d) + col) = v;
+      }
+      __threadfence_system();
+      __syncthreads();
+      if (tid < W) store_flag(peers.ws[tid], fl_comm_flag_index(L, par, rank, row_d), e);
+    }
+    if (tid == 0 && !wait_flag(me, fl_comm_flag_index(L, par, owner, row_d), e, budget)) s_fail = 1;
+    __syncthreads();
+    if (!s_fail) {
+      const uint16_t* src = reinterpret_cast<const uint16_t*>(me + fl_comm_inbox_offset(L)) + fl_comm_inbox_row(L, par, owner, row_d);
+      for (int col = tid * 8; col < D; col += 256 * 8)
+        *reinterpret_cast<uint4*>(out + t * D + col) = *reinterpret_cast<const uint4*>(src + col);
+      if (q_rank > 0) {
+        __syncthreads();   // the row is complete in `out` (this workgroup's own stores: visible to its wave 0)
+        if (tid < 64)
+          fl_norm::dual_rmsnorm_row(out + t * D, t, q_rank, kv_rank, gamma_q, gamma_kv, eps_q, eps_kv, x_norm_out, quant_out,
+                                    scale_out, ss_t, ss_g, tid);
+      }
+    }
+  } else if (tid < W) {
+    store_flag(peers.ws[tid], fl_comm_flag_index(L, par, W, rank), e);
+    if (!wait_flag(me, fl_comm_flag_index(L, par, W, tid), e, budget)) s_fail = 1;
+  }
+  __syncthreads();
+  if (s_fail) {
+    if (tid == 0) {
+      __hip_atomic_store(&st->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (t < T) poison();
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    const unsigned old = atomicAdd(&st->arrive, 1u);
+    if (old == gridDim.x - 1) {
+      st->arrive = 0;
+      __threadfence();
+      if (__hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u)
+        __hip_atomic_store(&st->epoch, e + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 int launch(FlComm* c, bool rs, const void* in, int64_t T, int H, const void* add_in, const void* residual_in, const void* gamma,
            float eps, void* residual_out, void* norm_out, void* quant_out, float* scale_out, int64_t ss_t, int64_t ss_g,
            fl_stream_t stream) {
@@ -325,6 +416,39 @@ extern "C" int fl_reducescatter_fused(void* comm, const void* in, int64_t T, int
                                       float* scale_out, int64_t s_stride_t, int64_t s_stride_g, fl_stream_t stream) {
   return launch((FlComm*)comm, true, in, T, H, add_in, residual_in, gamma, eps, residual_out, norm_out, quant_out, scale_out,
                 s_stride_t, s_stride_g, stream);
+}
+
+extern "C" int fl_allgather_fused(void* comm, const void* in, int64_t t_cur, int64_t T, int D, void* out, int q_rank, int kv_rank,
+                                  const void* gamma_q, const void* gamma_kv, float eps_q, float eps_kv, void* x_norm_out,
+                                  void* quant_out, float* scale_out, int64_t s_stride_t, int64_t s_stride_g, fl_stream_t stream) {
+  FlComm* c = (FlComm*)comm;
+  FL_CHECK_ARG(c != nullptr && c->connected, "one-shot comm: not connected (fl_comm_connect)");
+  if (__atomic_load_n(c->host_err, __ATOMIC_RELAXED) != 0u) {
+    fl_set_error("one-shot comm: an earlier launch timed out waiting for a peer (rank %d of %d); the communicator is dead, "
+                 "its outputs since then are NaN — re-create it", c->rank, c->world);
+    return FL_ERR_LAUNCH;
+  }
+  FL_CHECK_ARG(T >= 0 && T <= kMaxOneShotTokens && (T + c->world - 1) / c->world <= c->L.max_tokens,
+               "one-shot all-gather: T=%lld exceeds the workspace (max_tokens %lld per rank)", (long long)T, c->L.max_tokens);
+  const long long mine = fl_comm_slice_lo(T, c->world, c->rank + 1) - fl_comm_slice_lo(T, c->world, c->rank);
+  FL_CHECK_ARG(t_cur == mine, "one-shot all-gather: this rank holds %lld rows, get_num_tokens_per_rank gives it %lld of %lld",
+               (long long)t_cur, mine, (long long)T);
+  FL_CHECK_ARG(D > 0 && D % 8 == 0 && D <= c->L.hidden, "one-shot all-gather: D=%d (workspace hidden %d)", D, c->L.hidden);
+  FL_CHECK_ARG(out != nullptr && (in != nullptr || t_cur == 0), "one-shot all-gather: null tensor");
+  if (q_rank > 0) {
+    FL_CHECK_ARG(gamma_q && gamma_kv && q_rank % 8 == 0 && q_rank <= 2048 && kv_rank > 0 && kv_rank % 8 == 0 && kv_rank <= 1024 &&
+                     q_rank + kv_rank <= D, "one-shot all-gather: D=%d q_rank=%d kv_rank=%d", D, q_rank, kv_rank);
+    FL_CHECK_ARG(quant_out == nullptr || (scale_out != nullptr && q_rank % 128 == 0), "one-shot all-gather: quant needs scales");
+  }
+  Peers peers;
+  for (int p = 0; p < kMaxWorld; ++p) peers.ws[p] = p < c->world ? c->peer[p] : nullptr;
+  const unsigned long long budget = (unsigned long long)(c->timeout_s * 1e8);
+  oneshot_ag_kernel<<<dim3((unsigned)T + 1), 256, 0, (hipStream_t)stream>>>(
+      peers, c->rank, c->L, (const uint16_t*)in, T, D, (uint16_t*)out, q_rank, kv_rank, (const uint16_t*)gamma_q,
+      (const uint16_t*)gamma_kv, eps_q, eps_kv, (uint16_t*)x_norm_out, (uint8_t*)quant_out, scale_out, s_stride_t, s_stride_g, budget,
+      c->host_err_dev);
+  FL_CHECK_LAUNCH("oneshot_ag_kernel");
+  return FL_OK;
 }
 
 extern "C" int fl_comm_check(void* comm) {   // synchronises the device: not for the hot path

@@ -57,6 +57,12 @@ __device__ __forceinline__ void mfma_acc(v16f& acc, const v8i a, const v8i b, co
                : "v"(a), "v"(b), "v"(kUnit), "v"(sb));
 }
 
+#ifndef FL_GEMM2_PKMUL
+#define FL_GEMM2_PKMUL 0
+#endif
+#ifndef FL_GEMM2_PRIO
+#define FL_GEMM2_PRIO 1
+#endif
 #define G2_BARRIER()                          \
   do {                                        \
     __builtin_amdgcn_sched_barrier(0);        \
@@ -125,20 +131,25 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<const uint8_t*>(((unsigned long long)hi << 32) | lo);
   };
-  // Stage hs (may run past the last one: the source is clamped, the slot is idle by then — ONE body, constant vmcnt counts)
-  auto issue = [&](const int hs, const bool even) {
+  // Piece k of this wave's share of stage hs: 0, 1 = W pieces, 2, 3 = A pieces, 4 = the token scales of k block hs / 2
+  // (even stages only).  A stage past the last one re-fetches the last (clamped source; its slot is idle by then): ONE
+  // loop body, constant vmcnt counts.
+  auto issue_piece = [&](const int hs, const int k) {
     const int hc = hs < NH ? hs : NH - 1;
     uint8_t* s = smem + (hs & (kSlots - 1)) * kSlot + (2 * wave) * 1024;
-    const uint8_t* wb = uniform(w_base + (long long)hc * BKH);
-    const uint8_t* ab = uniform(a_base + (long long)hc * BKH);
-    fl_dma16_s(wb, voff_w0, s);
-    fl_dma16_s(wb, voff_w1, s + 1024);
-    fl_dma16_s(ab, voff_a0, s + kWHalf);
-    fl_dma16_s(ab, voff_a1, s + kWHalf + 1024);
-    if (even) {   // the token scales of k block hs / 2 travel with its first half
+    if (k == 0) fl_dma16_s(uniform(w_base + (long long)hc * BKH), voff_w0, s);
+    else if (k == 1) fl_dma16_s(uniform(w_base + (long long)hc * BKH), voff_w1, s + 1024);
+    else if (k == 2) fl_dma16_s(uniform(a_base + (long long)hc * BKH), voff_a0, s + kWHalf);
+    else if (k == 3) fl_dma16_s(uniform(a_base + (long long)hc * BKH), voff_a1, s + kWHalf + 1024);
+    else {
       const int kb = hs >> 1, kc = kb < KB ? kb : KB - 1;
       fl_dma4(as_src + (long long)kc * p.as_stride_k, smem + kSlots * kSlot + (kb & 1) * kAsSlot + wave * 256);
     }
+  };
+  auto issue = [&](const int hs, const bool even) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) issue_piece(hs, k);
+    if (even) issue_piece(hs, 4);
   };
 
   // operand read offsets: row li of a 32-row block (64 B per row), the lane half's 32 k bytes = chunks 2 lh, 2 lh + 1
@@ -160,9 +171,10 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   const float* wsrow = gWs + ((long long)e * ((p.N + BN - 1) / BN) + (n0 + 64 * wn) / BN) * KB;
   v8i wa[2], tb[4];
 
-  // ---- segment L: refill, operand reads, (first half of a k block:) scales + rescale of token blocks 2, 3 ----
+  // ---- segment L: operand reads, (first half of a k block:) scales + rescale of token blocks 2, 3.  No LDS-DMA here: the
+  //      four L waves of an interval would queue 18 pieces behind each other at the CU's vector-memory path (measured:
+  //      L segments of ~810 cycles, the slowest wave of a group sets the interval) — the refill rides behind the MFMAs ----
   auto seg_load = [&](const int h, const bool even, const bool first_kb) {
-    issue(h + 3, !even);   // (h + 3 is even iff h is odd)
     const uint8_t* sw = smem + (h & (kSlots - 1)) * kSlot + (64 * wn) * BKH;
     const uint8_t* sa = smem + (h & (kSlots - 1)) * kSlot + kWHalf + (128 * wm) * BKH;
     wa[0] = ld8(sw);
@@ -185,29 +197,46 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
         e8[j] = (int)eb;
       }
       if (!first_kb) {
-        // the MFMAs of these tiles were the FIRST of the previous M segment (>= 4 MFMA times ago) — margin for the
-        // XDL-write -> VALU-read rule that hipcc cannot see through the asm
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][2]), "+v"(acc[1][2]), "+v"(acc[0][3]), "+v"(acc[1][3]));
+        // the MFMAs of these tiles were the FIRST four of the previous M segment: complete long before this point (four
+        // more MFMAs, a barrier, the operand reads and the scale arithmetic lie in between) — the XDL-write -> VALU-read rule
+        // that hipcc cannot see through the asm is met by the schedule
+        asm volatile("" : "+v"(acc[0][2]), "+v"(acc[1][2]), "+v"(acc[0][3]), "+v"(acc[1][3]));
 #pragma unroll
         for (int j = 2; j < 4; ++j)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
+#if FL_GEMM2_PKMUL   // experiment: packed f32 multiplies in the L segment (this wave has no MFMA in flight here)
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f r2 = {ratio[j], ratio[j]};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              v2f x = {acc[i][j][2 * r], acc[i][j][2 * r + 1]};
+              asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x) : "v"(r2));
+              acc[i][j][2 * r] = x[0];
+              acc[i][j][2 * r + 1] = x[1];
+            }
+#else
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] *= ratio[j];
+#endif
             asm volatile("" : "+v"(acc[i][j]));
           }
       }
     }
   };
-  // ---- segment M: 8 MFMAs, token blocks 2, 3 first; in the first half of a k block the rescale of blocks 0, 1 rides in
-  //      the shadow of those MFMAs ----
-  auto seg_mma = [&](const bool even, const bool first_kb) {
-    __builtin_amdgcn_s_setprio(1);
+  // ---- segment M of half step h: 8 MFMAs, token blocks 2, 3 first, and this wave's pieces of stage h + 3, one behind an
+  //      MFMA each (the piece's issue stall hides under the 64 cycles of the MFMA in the pipe).  First half of a k block:
+  //      the rescale of blocks 0, 1 rides behind the first four MFMAs, the pieces behind the last four ----
+  auto seg_mma = [&](const int h, const bool even, const bool first_kb) {
+    if (FL_GEMM2_PRIO) __builtin_amdgcn_s_setprio(1);
     if (even && first_kb) {
 #pragma unroll
-      for (int j = 2; j < 6; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) mfma_zero(acc[i][j & 3], wa[i], tb[j & 3], e8[j & 3]);
+      for (int t = 0; t < 8; ++t) {
+        const int j = (2 + (t >> 1)) & 3, i = t & 1;
+        mfma_zero(acc[i][j], wa[i], tb[j], e8[j]);
+        if (t >= 4) issue_piece(h + 3, t - 4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -218,6 +247,8 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[ir][jr][r] *= ratio[jr];
           asm volatile("" : "+v"(acc[ir][jr]));
+        } else {
+          issue_piece(h + 3, t);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -225,9 +256,12 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
       for (int t = 0; t < 4; ++t) {
         const int j = t >> 1, i = t & 1;
         mfma_acc(acc[i][j], wa[i], tb[j], e8[j]);
+        if (even) issue_piece(h + 3, t);
+        else if (t == 0) issue_piece(h + 3, 4);   // (h odd: stage h + 3 is even — it carries the scales)
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (FL_GEMM2_PRIO) __builtin_amdgcn_s_setprio(0);
   };
 
 #ifdef FL_GEMM2_TIMING
@@ -253,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     GT(0);
     G2_BARRIER();
     GT(3);
-    seg_mma(true, first);
+    seg_mma(h, true, first);
     GT(1);
     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     GT(2);
@@ -263,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     GT(0);
     G2_BARRIER();
     GT(3);
-    seg_mma(false, false);
+    seg_mma(h + 1, false, false);
   };
   auto kblock_y = [&](const int kb, const bool first) __attribute__((always_inline)) {
     const int h = 2 * kb;
@@ -271,25 +305,26 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     G2_BARRIER();
     GT(3);
     seg_load(h, true, first);
-    // reads of slot h complete (group X refills it right after the next barrier) + this wave's pieces of stage h + 1
+    // reads of slot h complete (group X refills it right after the next barrier) + this wave's pieces of stage h + 1:
+    // only stage h + 2 (even: 5 pieces, issued in M of step h - 1) may stay in flight — stage h + 3 goes out in the M below
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     GT(0);
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     GT(2);
     G2_BARRIER();
     GT(3);
-    seg_mma(true, first);
+    seg_mma(h, true, first);
     GT(1);
     G2_BARRIER();
     GT(3);
     seg_load(h + 1, false, false);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     GT(0);
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage h + 3 (odd: 4 pieces) stays in flight
     GT(2);
     G2_BARRIER();
     GT(3);
-    seg_mma(false, false);
+    seg_mma(h + 1, false, false);
   };
   if (wm == 0) {   // ---------------- group X ----------------
     kblock_x(0, true);

@@ -40,67 +40,8 @@ __global__ __launch_bounds__(256) void dual_rmsnorm_kernel(uint16_t* __restrict_
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
-  uint16_t* r = ag + row * D;
-  // ---- q part (q_rank <= 2048) ----
-  {
-    float v[4][8];
-    float ssq = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int col = c * 512 + lane * 8;
-      if (col < q_rank) {
-        unpack8(*reinterpret_cast<const uint4*>(r + col), v[c]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ssq += v[c][i] * v[c][i];
-      }
-    }
-    ssq = wave_sum(ssq);
-    const float rinv = rsqrtf(ssq / (float)q_rank + eps_q);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int col = c * 512 + lane * 8;
-      if (col < q_rank) {
-        float g[8], y[8];
-        unpack8(*reinterpret_cast<const uint4*>(gamma_q + col), g);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] = fl_bf16_to_f32(fl_f32_to_bf16(v[c][i] * rinv * g[i]));
-        if (x_norm_out != nullptr) *reinterpret_cast<uint4*>(x_norm_out + row * q_rank + col) = pack8(y);
-        if (quant_out != nullptr) {
-          float s;
-          const uint2 q = quant_group(y, s);
-          *reinterpret_cast<uint2*>(quant_out + row * q_rank + col) = q;
-          if ((lane & 15) == 0) scale_out[row * ss_t + (col >> 7) * ss_g] = s;
-        }
-      }
-    }
-  }
-  // ---- kv part (kv_rank <= 1024), in place ----
-  {
-    float v[2][8];
-    float ssq = 0.f;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int col = c * 512 + lane * 8;
-      if (col < kv_rank) {
-        unpack8(*reinterpret_cast<const uint4*>(r + q_rank + col), v[c]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ssq += v[c][i] * v[c][i];
-      }
-    }
-    ssq = wave_sum(ssq);
-    const float rinv = rsqrtf(ssq / (float)kv_rank + eps_kv);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int col = c * 512 + lane * 8;
-      if (col < kv_rank) {
-        float g[8], y[8];
-        unpack8(*reinterpret_cast<const uint4*>(gamma_kv + col), g);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] = v[c][i] * rinv * g[i];
-        *reinterpret_cast<uint4*>(r + q_rank + col) = pack8(y);
-      }
-    }
-  }
+  dual_rmsnorm_row(ag + row * D, row, q_rank, kv_rank, gamma_q, gamma_kv, eps_q, eps_kv, x_norm_out, quant_out, scale_out, ss_t,
+                   ss_g, lane);
 }
 
 }  // namespace

@@ -128,4 +128,75 @@ __device__ __forceinline__ void add_rmsnorm_row(const uint16_t* __restrict__ xro
   }
 }
 
+// C7's row work (trtllm_allgather_fusion's dual RMSNorm, flashinfer_comm_fusion.py:613-638 <- layernorm.py:305-359) by ONE
+// WAVE: `r` = the gathered row [D]; cols [0, q_rank) -> x_norm_out row (separate tensor, optional 1x128 fp8 quant), cols
+// [q_rank, q_rank + kv_rank) normalised IN PLACE (the reference aliases y_norm_out onto allgather_out).  q_rank <= 2048,
+// kv_rank <= 1024.  Shared by norm_fused.hip (after an RCCL gather) and comm_oneshot.hip (after the peer-mapped gather).
+__device__ __forceinline__ void dual_rmsnorm_row(uint16_t* __restrict__ r, const long long row, const int q_rank, const int kv_rank,
+                                                 const uint16_t* __restrict__ gamma_q, const uint16_t* __restrict__ gamma_kv,
+                                                 const float eps_q, const float eps_kv, uint16_t* __restrict__ x_norm_out,
+                                                 uint8_t* __restrict__ quant_out, float* __restrict__ scale_out, const long long ss_t,
+                                                 const long long ss_g, const int lane) {
+  // ---- q part (q_rank <= 2048) ----
+  {
+    float v[4][8];
+    float ssq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (col < q_rank) {
+        unpack8(*reinterpret_cast<const uint4*>(r + col), v[c]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ssq += v[c][i] * v[c][i];
+      }
+    }
+    ssq = wave_sum(ssq);
+    const float rinv = rsqrtf(ssq / (float)q_rank + eps_q);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (col < q_rank) {
+        float g[8], y[8];
+        unpack8(*reinterpret_cast<const uint4*>(gamma_q + col), g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = fl_bf16_to_f32(fl_f32_to_bf16(v[c][i] * rinv * g[i]));
+        if (x_norm_out != nullptr) *reinterpret_cast<uint4*>(x_norm_out + row * q_rank + col) = pack8(y);
+        if (quant_out != nullptr) {
+          float s;
+          const uint2 q = quant_group(y, s);
+          *reinterpret_cast<uint2*>(quant_out + row * q_rank + col) = q;
+          if ((lane & 15) == 0) scale_out[row * ss_t + (col >> 7) * ss_g] = s;
+        }
+      }
+    }
+  }
+  // ---- kv part (kv_rank <= 1024), in place ----
+  {
+    float v[2][8];
+    float ssq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (col < kv_rank) {
+        unpack8(*reinterpret_cast<const uint4*>(r + q_rank + col), v[c]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ssq += v[c][i] * v[c][i];
+      }
+    }
+    ssq = wave_sum(ssq);
+    const float rinv = rsqrtf(ssq / (float)kv_rank + eps_kv);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (col < kv_rank) {
+        float g[8], y[8];
+        unpack8(*reinterpret_cast<const uint4*>(gamma_kv + col), g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = v[c][i] * rinv * g[i];
+        *reinterpret_cast<uint4*>(r + q_rank + col) = pack8(y);
+      }
+    }
+  }
+}
+
 }  // namespace fl_norm

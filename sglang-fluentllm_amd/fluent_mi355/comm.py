@@ -356,6 +356,19 @@ def trtllm_allgather_fusion(allgather_in, world_size, world_rank, hidden_dim, wo
     ws = _resolve(workspace_ptrs)
     W = _world(ws)
     t_cur, D = allgather_in.shape
+    osc = ws.oneshot
+    only_gather = pattern_code is not None and int(pattern_code) == int(AllGatherFusionPattern.kAllGather)
+    total = int(num_token_all_group) if num_token_all_group is not None else t_cur * W
+    if osc is not None and use_oneshot is not False and osc.world == W:
+        # one launch: peer-mapped push of every rank's rows + (C7) the dual RMSNorm on each gathered row
+        x = allgather_in.contiguous()
+        qr = 0 if only_gather else int(q_lora_rank)
+        if osc.accepts_gather(x, total, allgather_out, None if only_gather else x_norm_out, None if only_gather else quant_out,
+                              None if only_gather else scale_out, qr, 0 if only_gather else int(kv_lora_rank), x_rms_gamma, y_rms_gamma):
+            osc.allgather_fused(x, total, allgather_out, qr, 0 if only_gather else int(kv_lora_rank), x_rms_gamma, y_rms_gamma,
+                                x_rms_eps, y_rms_eps, None if only_gather else x_norm_out, None if only_gather else quant_out,
+                                None if only_gather else scale_out)
+            return
     if W == 1:
         allgather_out[:t_cur].copy_(allgather_in)
     else:
@@ -441,6 +454,24 @@ class TPDPConvertor:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = device if device is not None else (_device_of_group(group) if dist.is_initialized() else None) or (
             torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+        # decode-sized exchanges (<= 1024 rows) go through the peer-mapped one-shot transport of csrc/comm_oneshot.hip — one
+        # launch, no RCCL call — like C5/C6; larger ones keep the RCCL route below.  The constructor of OneShotComm is
+        # collective over the group and all-or-nothing (every rank of the reference builds its TPDPConvertor at the same
+        # point of start-up, dp_attention.py:97-131).  FLUENT_ONESHOT=0 disables, =1 also builds it at world 1 (tests).
+        self.oneshot = None
+        want = os.environ.get("FLUENT_ONESHOT", "auto")
+        multi = dist.is_initialized() and self.world > 1 and dist.get_backend(group) == "nccl"
+        if want != "0" and self.device.type == "cuda" and dtype == torch.bfloat16 and (multi or want == "1") \
+                and params.hidden_size % 8 == 0 and params.hidden_size <= 8192:
+            from .oneshot import MAX_ONESHOT_TOKENS, OneShotComm
+            try:
+                self.oneshot = OneShotComm(self.rank if multi else 0, self.world if multi else 1,
+                                           max(1, min(MAX_ONESHOT_TOKENS, int(params.max_num_tokens or MAX_ONESHOT_TOKENS))),
+                                           params.hidden_size, group=group)
+            except RuntimeError as ex:
+                import warnings
+
+                warnings.warn(f"fluent_mi355: one-shot TPDPConvertor unavailable ({ex}); using the RCCL route for every size")
 
     def get_token_dist(self, total):
         return get_num_tokens_per_rank(self.world, total)
@@ -455,6 +486,11 @@ class TPDPConvertor:
 
     def reduce_scatter(self, ctx, stream=None):
         W, mine, H = self.world, ctx.counts[self.rank], self.p.hidden_size
+        osc = self.oneshot
+        if osc is not None and osc.world == W and osc.fits(ctx.input().shape[0], H, reduce_scatter=True) \
+                and osc.accepts(ctx.input(), True, residual_out=ctx.output()):
+            osc.reducescatter_fused(ctx.input(), residual_out=ctx.output())   # sum of the W pieces of this rank's slice, one launch
+            return
         if W == 1:
             ctx.output().copy_(ctx.input())
             return
@@ -473,6 +509,10 @@ class TPDPConvertor:
 
     def all_gather(self, ctx, stream=None):
         W, mine = self.world, ctx.counts[self.rank]
+        osc = self.oneshot
+        if osc is not None and osc.world == W and osc.accepts_gather(ctx.input(), sum(ctx.counts), ctx.output()):
+            osc.allgather_fused(ctx.input(), sum(ctx.counts), ctx.output())
+            return
         if W == 1:
             ctx.output().copy_(ctx.input())
             return

@@ -25,10 +25,11 @@ lib.fl_comm_connect.argtypes = [_vp, _vp]
 lib.fl_comm_set_timeout.argtypes = [_vp, ctypes.c_double]
 lib.fl_allreduce_fused.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i64, _vp]
 lib.fl_reducescatter_fused.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i64, _vp]
+lib.fl_allgather_fused.argtypes = [_vp, _vp, _i64, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i64, _i64, _vp]
 lib.fl_comm_check.argtypes = [_vp]
 lib.fl_comm_destroy.argtypes = [_vp]
 for _n in ("fl_comm_create", "fl_comm_local_handle", "fl_comm_connect", "fl_comm_set_timeout", "fl_allreduce_fused",
-           "fl_reducescatter_fused", "fl_comm_check", "fl_comm_destroy"):
+           "fl_reducescatter_fused", "fl_allgather_fused", "fl_comm_check", "fl_comm_destroy"):
     getattr(lib, _n).restype = _i32
 
 
@@ -145,6 +146,48 @@ class OneShotComm:
         check(lib.fl_reducescatter_fused(self._h, x.data_ptr(), T, H, _p(add_in), _p(residual_in), _p(gamma), float(eps),
                                          _p(residual_out), _p(norm_out), _p(quant_out), _p(scale_out), st, sg, stream_ptr(x.device)),
               "fl_reducescatter_fused")
+
+    def accepts_gather(self, x, total, out, x_norm_out=None, quant_out=None, scale_out=None, q_rank=0, kv_rank=0,
+                       gamma_q=None, gamma_kv=None):
+        """the raw-pointer contract of allgather_fused: bf16 contiguous [rows of this rank, D] -> out [total, D] (bf16,
+        contiguous, same device); dual-norm outputs [total, q_rank]"""
+        if x.dim() != 2 or x.dtype != torch.bfloat16 or not x.is_cuda or not x.is_contiguous():
+            return False
+        D = x.shape[1]
+        if x.shape[0] != self.slice_rows(total, True) or total > MAX_ONESHOT_TOKENS or -(-total // self.world) > self.max_tokens:
+            return False
+        if D % 8 or D > self.hidden:
+            return False
+        if (out.dtype != torch.bfloat16 or not out.is_contiguous() or out.device != x.device or out.dim() != 2
+                or out.shape[0] < total or out.shape[1] != D):
+            return False
+        if q_rank:
+            for g_, n_ in ((gamma_q, q_rank), (gamma_kv, kv_rank)):
+                if g_ is None or g_.dtype != torch.bfloat16 or not g_.is_contiguous() or g_.device != x.device or g_.numel() != n_:
+                    return False
+            if x_norm_out is not None and (x_norm_out.dtype != torch.bfloat16 or not x_norm_out.is_contiguous()
+                                           or x_norm_out.device != x.device or x_norm_out.dim() != 2
+                                           or x_norm_out.shape[0] < total or x_norm_out.shape[1] != q_rank):
+                return False
+            if quant_out is not None:
+                if (quant_out.element_size() != 1 or not quant_out.is_contiguous() or quant_out.device != x.device
+                        or quant_out.dim() != 2 or quant_out.shape[0] < total or quant_out.shape[1] != q_rank or q_rank % 128):
+                    return False
+                if (scale_out is None or scale_out.dtype != torch.float32 or scale_out.device != x.device or scale_out.dim() != 2
+                        or scale_out.shape[0] < total or scale_out.shape[1] < q_rank // 128):
+                    return False
+        return True
+
+    def allgather_fused(self, x, total, out, q_rank=0, kv_rank=0, gamma_q=None, gamma_kv=None, eps_q=1e-6, eps_kv=1e-6,
+                        x_norm_out=None, quant_out=None, scale_out=None):
+        """every rank's rows `x` [get_num_tokens_per_rank(world, total)[rank], D] -> out[:total] in rank order, one launch;
+        q_rank > 0: + the dual RMSNorm of C7 on every gathered row (csrc/comm_oneshot.hip oneshot_ag_kernel)"""
+        self._require(self.accepts_gather(x, total, out, x_norm_out, quant_out, scale_out, q_rank, kv_rank, gamma_q, gamma_kv),
+                      "allgather_fused")
+        st, sg = self._strides(scale_out)
+        check(lib.fl_allgather_fused(self._h, x.data_ptr() if x.numel() else None, x.shape[0], int(total), x.shape[1], out.data_ptr(),
+                                     int(q_rank), int(kv_rank), _p(gamma_q), _p(gamma_kv), float(eps_q), float(eps_kv),
+                                     _p(x_norm_out), _p(quant_out), _p(scale_out), st, sg, stream_ptr(x.device)), "fl_allgather_fused")
 
     def check(self):
         """synchronises; raises if a flag wait ever timed out (a peer died or issued a different sequence of operations)"""

@@ -260,6 +260,68 @@ def test_oneshot_two_processes_on_one_gpu_hipipc():
     assert r.stdout.count("parity OK") == 2, r.stdout[-2000:]
 
 
+def test_oneshot_allgather_and_dual_rmsnorm_world1_match_the_collective_route(monkeypatch):
+    """C7 / C3 on the one-shot transport at world 1 (FLUENT_ONESHOT=1): flashinfer.comm.trtllm_allgather_fusion (gather only, and
+    gather + dual RMSNorm + fp8 quant) and TPDPConvertor.reduce_scatter / all_gather give the bits of the RCCL-route kernels;
+    vllm_ar.all_reduce sums in place through fl_allreduce_fused."""
+    import flashinfer.comm as comm
+    from flashinfer.comm import vllm_ar
+    from fluent_mi355.comm import HipNormOps, TPDPConvertor
+    T, D, QR, KVR = 37, 2112, 1536, 512
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(T, D, generator=g).to(torch.bfloat16).to(DEV)
+    gq, gkv = torch.rand(QR, generator=g).to(torch.bfloat16).to(DEV), torch.rand(KVR, generator=g).to(torch.bfloat16).to(DEV)
+    got = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("FLUENT_ONESHOT", flag)
+        handles, wsp = comm.trtllm_create_ipc_workspace_for_all_reduce_fusion(0, 1, 64, 7168)
+        assert (handles[0].oneshot is not None) == (flag == "1")
+        ag = torch.zeros(T, D, dtype=torch.bfloat16, device=DEV)
+        comm.trtllm_allgather_fusion(allgather_in=x, world_size=1, world_rank=0, hidden_dim=D, workspace_ptrs=wsp,
+                                     num_token_current_rank=T, allgather_out=ag, num_token_all_group=T,
+                                     pattern_code=comm.AllGatherFusionPattern.kAllGather)
+        assert torch.equal(ag, x)
+        ag2 = torch.zeros_like(ag)
+        xn = torch.zeros(T, QR, dtype=torch.bfloat16, device=DEV)
+        q = torch.zeros(T, QR, dtype=torch.float8_e4m3fn, device=DEV)
+        sc = torch.zeros(T, QR // 128, device=DEV)
+        comm.trtllm_allgather_fusion(allgather_in=x, world_size=1, world_rank=0, hidden_dim=D, workspace_ptrs=wsp,
+                                     num_token_current_rank=T, allgather_out=ag2, num_token_all_group=T,
+                                     pattern_code=comm.AllGatherFusionPattern.kAllGatherfusedRMSFP8BlockWiseQuant,
+                                     x_norm_out=xn, y_norm_out=ag2, quant_out=q, scale_out=sc, x_rms_gamma=gq, y_rms_gamma=gkv,
+                                     x_rms_eps=1e-6, y_rms_eps=1e-6, q_lora_rank=QR, kv_lora_rank=KVR, qk_rope_head_dim=64)
+        torch.cuda.synchronize()
+        got.append([ag2.clone(), xn.clone(), q.view(torch.uint8).clone(), sc.clone()])
+        if handles[0].oneshot is not None:
+            handles[0].oneshot.check()
+        comm.trtllm_destroy_ipc_workspace_for_all_reduce_fusion(handles)
+    for a, b in zip(*got):
+        assert torch.equal(a, b)
+    assert not torch.equal(got[0][0][:, QR:QR + KVR], x[:, QR:QR + KVR])      # the kv columns were normalised in place
+    # TPDPConvertor + vllm_ar at world 1 on the one-shot transport
+    monkeypatch.setenv("FLUENT_ONESHOT", "1")
+    cv = TPDPConvertor(TPDPConvertor.Params(0, 64, 1, 7168), device=torch.device(DEV))
+    assert cv.oneshot is not None
+    rs = cv.get_reduce_scatter_context(29)
+    rs.input().copy_(torch.randn(29, 7168, generator=g).to(torch.bfloat16))
+    cv.reduce_scatter(rs)
+    agc = cv.get_all_gather_context(29)
+    agc.input().copy_(rs.output())
+    cv.all_gather(agc)
+    torch.cuda.synchronize()
+    assert torch.equal(rs.output(), rs.input()) and torch.equal(agc.output(), rs.input())
+    cv.oneshot.check()
+    h = vllm_ar.init_custom_ar([], torch.empty(0), 0, True)
+    y = torch.randn(17, 7168, generator=g).to(torch.bfloat16).to(DEV)
+    y0 = y.clone()
+    vllm_ar.all_reduce(h, y, y)
+    z = torch.empty_like(y)
+    vllm_ar.all_reduce(h, y, z)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0) and torch.equal(z, y0)
+    vllm_ar.dispose(h)
+
+
 def test_oneshot_lost_peer_poisons_outputs_and_raises():
     """A peer that never issues an operation: the waiting rank's launch ends after its time budget with NaN in every output
     row (never partial sums), the epoch is not advanced, the next launch call and check() raise, and the late rank fails

@@ -33,8 +33,22 @@ def worker(rank, world, port, T, H, iters):
         lo = sum(counts[:rank]); hi = lo + counts[rank]
         r_res, r_norm = torch.empty(hi - lo, H, dtype=torch.bfloat16, device=dev), torch.empty(hi - lo, H, dtype=torch.bfloat16, device=dev)
         c.reducescatter_fused(xs[rank].to(dev), None, res[lo:hi].contiguous(), gamma, 1e-6, r_res, r_norm)
+        # one-shot all-gather (C3) and all-gather + dual RMSNorm (C7) of the uneven row split, against the kernel of the RCCL route
+        D, QR, KVR = 2112, 1536, 512
+        full = torch.randn(T, D, generator=g).to(torch.bfloat16).to(dev)
+        gq, gkv = torch.rand(QR, generator=g).to(torch.bfloat16).to(dev), torch.rand(KVR, generator=g).to(torch.bfloat16).to(dev)
+        ag = torch.zeros(T, D, dtype=torch.bfloat16, device=dev)
+        c.allgather_fused(full[lo:hi].contiguous(), T, ag)
+        e_ag, e_x = full.clone(), torch.empty(T, QR, dtype=torch.bfloat16, device=dev)
+        e_q, e_s = torch.empty(T, QR, dtype=torch.float8_e4m3fn, device=dev), torch.empty(T, QR // 128, device=dev)
+        ops.dual_rmsnorm(e_ag, QR, KVR, gq, gkv, 1e-6, 1e-6, e_x, e_q, e_s)
+        ag2, x2 = torch.zeros_like(ag), torch.zeros_like(e_x)
+        q2, s2 = torch.zeros_like(e_q), torch.zeros_like(e_s)
+        c.allgather_fused(full[lo:hi].contiguous(), T, ag2, QR, KVR, gq, gkv, 1e-6, 1e-6, x2, q2, s2)
         c.check()
         ok &= torch.equal(o_res, e_res) and torch.equal(o_norm, e_norm) and torch.equal(r_res, e_res[lo:hi]) and torch.equal(r_norm, e_norm[lo:hi])
+        ok &= torch.equal(ag, full) and torch.equal(ag2, e_ag) and torch.equal(x2, e_x)
+        ok &= torch.equal(q2.view(torch.uint8), e_q.view(torch.uint8)) and torch.equal(s2, e_s)
     # latency of the fused all-reduce (graph of 20 launches)
     x = xs[rank].to(dev)
     for _ in range(3): c.allreduce_fused(x, res, gamma, 1e-6, o_res, o_norm)
@@ -111,4 +125,4 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "lostpeer":
         mp.spawn(lost_peer_worker, args=(2, port, 16, 2048), nprocs=2, join=True)
     else:
-        mp.spawn(worker, args=(world, port, 48, 7168, 5), nprocs=world, join=True)
+        mp.spawn(worker, args=(world, port, 49 if world == 2 else 48, 7168, 5), nprocs=world, join=True)   # 49 rows over 2 ranks: 25 / 24
