@@ -61,7 +61,7 @@ __device__ __forceinline__ void mfma_acc(v16f& acc, const v8i a, const v8i b, co
 #define FL_GEMM2_PKMUL 0
 #endif
 #ifndef FL_GEMM2_PRIO
-#define FL_GEMM2_PRIO 1
+#define FL_GEMM2_PRIO 0   // measured (profiles/r03_gemm_big2_variants_ab.txt): +2 % without the priority flips
 #endif
 #define G2_BARRIER()                          \
   do {                                        \
@@ -82,6 +82,10 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int wn = wave & 3, wm = wave >> 2;
+#ifdef FL_GEMM2_TIMING
+  const unsigned long long t_entry = __builtin_readcyclecounter();
+  const unsigned long long w_entry = wall_clock64();
+#endif
 
   // ---- XCD-aware tile order (speed only): workgroup b runs on XCD b % 8; within a round of 256 workgroups XCD x takes
   //      the logical tiles [32x, 32x + 32) of the round.  The last, partial round keeps the identity order. ----
@@ -341,10 +345,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     GT(1);
   }
 #ifdef FL_GEMM2_TIMING
-  if (g_g2dbg != nullptr && lane == 0 && blockIdx.x < 4096) {
-    unsigned long long* d = g_g2dbg + ((long long)blockIdx.x * 8 + wave) * 8;
-    d[0] = gt[0]; d[1] = gt[1]; d[2] = gt[2]; d[3] = gt[3]; d[4] = __builtin_readcyclecounter() - g0;
-  }
+  const unsigned long long t_loop_end = __builtin_readcyclecounter();
 #endif
 
   // ---- epilogue: D^T[n, m] -> out[m, n] bf16; lane (m = token li of block j, half lh) holds n = 8g + 4lh + (0..3) ----
@@ -373,6 +374,16 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
       }
     }
   }
+#ifdef FL_GEMM2_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (g_g2dbg != nullptr && lane == 0 && blockIdx.x < 8192) {
+    unsigned long long* d = g_g2dbg + ((long long)blockIdx.x * 8 + wave) * 8;
+    d[0] = gt[0]; d[1] = gt[1]; d[2] = gt[2]; d[3] = gt[3]; d[4] = t_loop_end - g0;
+    d[5] = g0 - t_entry;                                   // tile lookup + address set-up
+    d[6] = __builtin_readcyclecounter() - t_loop_end;      // epilogue incl. the wait for its stores
+    d[7] = w_entry;                                        // wall clock (100 MHz) at entry: workgroup start times
+  }
+#endif
 }
 
 }  // namespace

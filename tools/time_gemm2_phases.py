@@ -18,7 +18,7 @@ A = torch.randint(0, 120, (M, K), device=dev, generator=g, dtype=torch.uint8).vi
 As = torch.rand(M, K // 128, device=dev, generator=g)
 ex = (torch.arange(E + 1, device=dev) * R).to(torch.int32)
 out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-dbg = torch.zeros(4096 * 8 * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(8192 * 8 * 8, dtype=torch.int64, device=dev)
 lib.fl_gemm2_debug_set_buffer.argtypes = [ctypes.c_void_p]
 lib.fl_gemm2_debug_set_buffer(dbg.data_ptr())
 for _ in range(3):
@@ -34,4 +34,12 @@ for name, sl in (("group X (waves 0-3)", slice(0, 4)), ("group Y (waves 4-7)", s
     x = d[:, sl, :].reshape(-1, 8)
     print(f"{name}: per k block (cycles): L segments {x[:,0].mean()/KB:.0f}  M segments {x[:,1].mean()/KB:.0f}  vmcnt waits {x[:,2].mean()/KB:.0f}  "
           f"barriers {x[:,3].mean()/KB:.0f}  loop total {x[:,4].mean()/KB:.0f}")
+x = d.reshape(-1, 8)
+nwg = d.shape[0]
+w = d[:, 0, 7]
+starts = np.sort(w - w.min()) / 100.0   # us
+rounds = max(1, nwg // 256)
+print(f"workgroups {nwg}: set-up {x[:,5].mean():.0f} cycles, k loop {x[:,4].mean():.0f}, epilogue {x[:,6].mean():.0f} (max {x[:,6].max():.0f}); "
+      f"workgroup start times (us): first round ends {starts[min(255, nwg-1)]:.1f}, median {np.median(starts):.1f}, last {starts[-1]:.1f}; kernel {ms*1e3:.1f} us "
+      f"-> {ms*1e3/rounds:.1f} us per round of 256")
 print(f"{os.environ.get('GT_LIB','G2T')} N={N} K={K} M={M}: {ms:.3f} ms = {2.0*M*N*K/ms/1e9:.0f} TFLOP/s (timing build)")
