@@ -281,12 +281,10 @@ def get_mla_metadata(cache_seqlens, num_parts: int, page_size: int = PAGE_SIZE):
 # The exact oracle above bounds the end-to-end error (FP8 tolerance); this one pins the design:
 # per page, the two 32-token halves keep independent integer references m_W = ceil(running max
 # of y)+2, y = s*log2e + log2(k_scale[t]); P' = 2^(y - m_W + 8) is rounded to e4m3 (RNE);
-# O accumulates 2^(m_W - M) * P'_q * k8 (exact powers of two).  ONE normaliser (round 3): lq sums
+# O accumulates 2^(m_W - M) * P'_q * k8 (exact powers of two).  Two normalisers per half: lq_W sums
 # the ROUNDED P'_q/k_scale[t] (divides O: the weights of the quantised numerator sum to exactly 1,
-# so e.g. a 1-token sequence returns its latent exactly) and also gives the returned LSE — the LSE
-# of the rounded weights, within log(1 + 2^-4) = 0.061 of the exact one for a single token and
-# closer as 1/sqrt(N_eff) (the reference's backend discards the LSE, flashmla_backend.py:208-224).
-# Differences to the GPU are fp32-vs-fp64 accumulation and exp2 ulps only.
+# so e.g. a 1-token sequence returns its latent exactly), lx_W sums the unrounded P'/k_scale[t]
+# (exact LSE).  Differences to the GPU are fp32-vs-fp64 accumulation and exp2 ulps only.
 # --------------------------------------------------------------------------------------
 def mla_decode_fp8_per_token_emulated(q_nope, q_scale, q_rope, k_lora, k_scale, k_rope, block_table,
                                       cache_seqlens, softmax_scale, causal=True, page_size=PAGE_SIZE):
@@ -346,9 +344,7 @@ def mla_decode_fp8_per_token_emulated(q_nope, q_scale, q_rope, k_lora, k_scale, 
         ok = l > 0
         okq = lq > 0
         out[b][okq] = O[okq] / lq[okq][:, None]
-        # round 3: the kernel returns the LSE of the ROUNDED weights (its only normaliser; the exact sum `l` is kept here as
-        # the statement of what the rounded one approximates: |lse_q - lse_exact| <= log(1 + 2^-4))
-        lse[b][okq] = (torch.log2(lq[okq]) + M[okq] - 8.0) * math.log(2.0)
+        lse[b][ok] = (torch.log2(l[ok]) + M[ok] - 8.0) * math.log(2.0)
     return out.reshape(bs, s_q, H, dn), lse.reshape(bs, s_q, H).permute(0, 2, 1).contiguous()
 
 

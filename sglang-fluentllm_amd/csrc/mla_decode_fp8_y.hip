@@ -33,11 +33,9 @@ constexpr int kPbufPerParity = 2 * 2 * 64 * 16;                    // [rt 2][W 2
 constexpr int kOffPbuf = kOffRing + kRingSlots * kSlotBytes;       // [parity 2]
 constexpr int kRefPerParity = 2 * 2 * 32 * 4;                      // [rt 2][W 2][32 rows] f32
 constexpr int kOffRef = kOffPbuf + 2 * kPbufPerParity;             // [parity 2]
-constexpr int kScratchPerWave = 3 * 3 * 32 * 4;                    // [page mod 3] {ks, log2 ks, 1/ks} x 32 tokens (three buffers:
-                                                                   // the QK wave reads page i and writes page i+1 while the PV
-                                                                   // waves read 1/ks of page i-1 for the normaliser)
+constexpr int kScratchPerWave = 2 * 3 * 32 * 4;                    // [page parity 2] {ks, log2 ks, 1/ks} x 32 tokens
 constexpr int kOffScratch = kOffRef + 2 * kRefPerParity;           // [QK wave 4]
-constexpr int kOffLm = kOffScratch + 4 * kScratchPerWave;          // [rt 2][W 2][3][32] f32: (unused, unused, m) per row
+constexpr int kOffLm = kOffScratch + 4 * kScratchPerWave;          // [rt 2][W 2][3][32] f32: l, lq, m per row
 constexpr int kOffFlag = kOffLm + 2 * 2 * 3 * 32 * 4;              // 4 ints: redo votes of the PV waves
 constexpr int kOffQr = kOffFlag + 16;                                 // [QK wave 4][4 k-steps][64 lanes] 16 B: Q rope fragments
 constexpr int kOffMerge = kOffQr + 4 * 4096;                            // 2 ints: PV-wave arrivals, merge verdict (in-kernel split merge)
@@ -110,7 +108,7 @@ __device__ __forceinline__ void scale_prep(float* __restrict__ scratch, float ks
 //      go out behind the MFMA issue (into the registers the rope MFMAs just read), the normaliser sums and the next
 //      page's triples follow the P' store.  s_setprio 1 around the MFMA chain: the PV wave of this SIMD has its 8
 //      MFMAs ready at the same time, and they belong beside this wave's softmax, not inside its chain. ----
-__device__ __forceinline__ void qk_step(float& m_w, const QkLane& lc, const int lane,
+__device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w, const QkLane& lc, const int lane,
                                         const v8i (&qn)[8], const uint8_t* __restrict__ qr_lds, const float qs, RopeRegs& rr,
                                         const float ks_next, const uint8_t* __restrict__ rope_next,
                                         const float* __restrict__ scale_next, const uint8_t* __restrict__ pf_next,
@@ -183,7 +181,7 @@ __device__ __forceinline__ void qk_step(float& m_w, const QkLane& lc, const int 
   // the scale triples of the lane's 16 tokens take over the operand registers of k-steps 0..3 behind the MFMAs of
   // k-steps 4..7, so that they have landed when the chain drains ({ks, log2 ks} now, 1/ks behind the scaling: 48
   // registers at once do not fit beside Q and the rope buffers)
-  float4 ks4[4], lk4[4];
+  float4 ks4[4], lk4[4], ik4[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int tb = g * 8 + lh * 4;
@@ -290,6 +288,8 @@ __device__ __forceinline__ void qk_step(float& m_w, const QkLane& lc, const int 
     }
   }
   FL_T(9);   // MFMA drain + scaling + max (lanes)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) ik4[g] = *reinterpret_cast<const float4*>(scratch + 64 + g * 8 + lh * 4);
   {
     // max over the two lane halves without an LDS round trip: v_permlane32_swap exchanges lanes 32..63 of its first
     // operand with lanes 0..31 of its second
@@ -317,10 +317,25 @@ __device__ __forceinline__ void qk_step(float& m_w, const QkLane& lc, const int 
   ref_w[li] = m_new;   // (identical in both lane halves)
   __builtin_amdgcn_sched_barrier(0);
   FL_T(10);  // exp + quantise + publish
-  // ---- off the critical path: the next page's scale triples.  (Round 3: the normaliser left this wave — the PV waves sum
-  //      the ROUNDED weights P'_q / k_scale from the very bytes they feed the PV MFMA, in the units of their fixed O
-  //      reference (pv_step); the unrounded second normaliser is gone: the LSE is that of the rounded weights.) ----
-  m_w = m_new;
+  // ---- off the critical path: the two normalisers, then the next page's scale triples ----
+  {
+    const float f = __builtin_amdgcn_exp2f(m_w - m_new);   // exactly 1 when the reference did not move
+    // two partial sums each, as PACKED f32 math (v_pk_fma_f32: nothing of this wave runs on the matrix pipe here)
+    float2v l2 = {l_run * f, 0.f}, q2 = {lq_run * f, 0.f};
+    m_w = m_new;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float2v ik01 = {ik4[g].x, ik4[g].y}, ik23 = {ik4[g].z, ik4[g].w};
+      // unrounded sum: exact LSE
+      l2 = __builtin_elementwise_fma(float2v{ev[g * 4 + 0], ev[g * 4 + 1]}, ik01, l2);
+      l2 = __builtin_elementwise_fma(float2v{ev[g * 4 + 2], ev[g * 4 + 3]}, ik23, l2);
+      // the ROUNDED weights normalise O (numerator and denominator use the same weights: they sum to exactly 1)
+      q2 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(pk[g], false), ik01, q2);
+      q2 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(pk[g], true), ik23, q2);
+    }
+    l_run = l2[0] + l2[1];
+    lq_run = q2[0] + q2[1];
+  }
 #if !FL_Y_TAIL_IN_CHAIN
   scale_prep(scratch_next, ks_next, tok0w + kPage, li, L);
 #endif
@@ -334,10 +349,9 @@ __device__ __forceinline__ void qk_step(float& m_w, const QkLane& lc, const int 
 // with m_o preset to the final reference.
 constexpr float kMaxUp = 64.f;
 template <bool DMA, int FMT>
-__device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, float* __restrict__ lq_lds, int& redo, const PvLane& lc_in, const int lane,
+__device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, const PvLane& lc_in, const int lane,
                                         const uint8_t* __restrict__ vp, const uint8_t* __restrict__ pbuf_rt,
-                                        const float* __restrict__ ref_rt, const float* __restrict__ ik_w0,
-                                        const float* __restrict__ ik_w1, const uint8_t* __restrict__ src_nope,
+                                        const float* __restrict__ ref_rt, const uint8_t* __restrict__ src_nope,
                                         uint8_t* __restrict__ dma_dst FL_T_PARAMS) {
   const int li = lane & 31, lh = lane >> 5;
   // opaque copy of the lane constants: nothing derived from them is hoisted out of the page loop (and spilled)
@@ -360,42 +374,6 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, float* __restr
     for (int k = 0; k < FL_Y_DMA_FIRST; ++k) fl_dma16_s(src_nope, dn_off<FMT>(lc, k), dma_dst + k * 1024);
   }
 #endif
-  const float mw_max = fmaxf(m0, m1);
-  m_o = m_o > kNegRef ? m_o : mw_max;
-  redo |= (mw_max - m_o > kMaxUp) ? 1 : 0;
-  int sb = 127 + (int)fminf((lh ? m1 : m0) - m_o, kMaxUp);
-  sb = sb < 0 ? 0 : sb;
-  const v8i pb = make_v8i(p0, p1);
-  // (the normaliser comes BEFORE the V^T operand loads: its temporaries are dead when the 24 operand registers go live —
-  //  placed behind them hipcc spilled the lane constants of the refill into scratch, reloaded inside the page loop)
-  // ---- the normaliser, in the units of the fixed O reference: lq_o += sum_t P'_q[t] / k_scale[t] * 2^(m_block - m_o) over
-  //      this lane's 16 tokens of each block (tokens 8g + 4lh + e of block W: the bytes of p0 / p1; the other lane half holds
-  //      the other 16 — added up once in the epilogue).  These are the ROUNDED weights the MFMA below multiplies V with, so
-  //      numerator and denominator carry the same weights (they sum to exactly 1).  FMT 1 has no per-token scales. ----
-  {
-    float2v s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
-    const unsigned w0[4] = {p0.x, p0.y, p0.z, p0.w}, w1[4] = {p1.x, p1.y, p1.z, p1.w};
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if constexpr (FMT == 1) {
-        s0 = s0 + __builtin_amdgcn_cvt_pk_f32_fp8(w0[g], false) + __builtin_amdgcn_cvt_pk_f32_fp8(w0[g], true);
-        s1 = s1 + __builtin_amdgcn_cvt_pk_f32_fp8(w1[g], false) + __builtin_amdgcn_cvt_pk_f32_fp8(w1[g], true);
-      } else {
-        const float4 k0 = *reinterpret_cast<const float4*>(ik_w0 + g * 8 + lh * 4);
-        const float4 k1 = *reinterpret_cast<const float4*>(ik_w1 + g * 8 + lh * 4);
-        s0 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(w0[g], false), float2v{k0.x, k0.y}, s0);
-        s0 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(w0[g], true), float2v{k0.z, k0.w}, s0);
-        s1 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(w1[g], false), float2v{k1.x, k1.y}, s1);
-        s1 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(w1[g], true), float2v{k1.z, k1.w}, s1);
-      }
-    }
-    // (an empty block has reference kNegRef and all-zero P': its factor underflows to 0 and the sum is 0 anyway)
-    const float fA = __builtin_amdgcn_exp2f(fminf(m0 - m_o, kMaxUp)), fB = __builtin_amdgcn_exp2f(fminf(m1 - m_o, kMaxUp));
-    // accumulated IN LDS (ds_add_f32 on the lane's own slot: no race, and no register that lives across the page loop —
-    // with one more long-lived VGPR hipcc spilled the refill's lane constants and reloaded them inside the loop)
-    __hip_atomic_fetch_add(lq_lds + lane, fmaf(s0[0] + s0[1], fA, (s1[0] + s1[1]) * fB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  __builtin_amdgcn_sched_barrier(0);
   v8i va[8];
   auto load_vt = [&](int jb) {
 #ifdef FL_Y_HALFV   // experiment: half of the V^T operand reads (results are garbage)
@@ -420,6 +398,12 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, float* __restr
   m_o = fmaxf(m_o, m0 + m1 + __uint_as_float(p0.x ^ p1.x));
   return;
 #endif
+  const float mw_max = fmaxf(m0, m1);
+  m_o = m_o > kNegRef ? m_o : mw_max;
+  redo |= (mw_max - m_o > kMaxUp) ? 1 : 0;
+  int sb = 127 + (int)fminf((lh ? m1 : m0) - m_o, kMaxUp);
+  sb = sb < 0 ? 0 : sb;
+  const v8i pb = make_v8i(p0, p1);
 #if FL_Y_MID_BARRIER
   __builtin_amdgcn_s_barrier();   // M_i: the QK chains are issued
   FL_T(6);
@@ -447,7 +431,7 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, float* __restr
 //      NINTH fp8 k-step whose A operand comes straight from bytes 512..575 of the token's row in global memory (two pages
 //      ahead, like the bf16 rope of the per-token format); there are no per-token scales — the device-scalar descales are
 //      folded into qs (scores) and into the epilogue (V).  Same block-reference / P' arithmetic as qk_step. ----
-__device__ __forceinline__ void qk_step1(float& m_w, const QkLane& lc, const int lane,
+__device__ __forceinline__ void qk_step1(float& l_run, float& lq_run, float& m_w, const QkLane& lc, const int lane,
                                          const v8i (&qn)[8], const v8i& qr8, const float qs, RopeRegs& rr,
                                          const uint8_t* __restrict__ rope_next, const uint8_t* __restrict__ kp,
                                          uint8_t* __restrict__ pbuf_w, float* __restrict__ ref_w, const int tok0w,
@@ -518,7 +502,18 @@ __device__ __forceinline__ void qk_step1(float& m_w, const QkLane& lc, const int
   *reinterpret_cast<uint4*>(pbuf_w + lane * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
   ref_w[li] = m_new;
   __builtin_amdgcn_sched_barrier(0);
-  m_w = m_new;   // (the normaliser is summed by the PV waves from the published bytes: pv_step)
+  {
+    const float f = __builtin_amdgcn_exp2f(m_w - m_new);
+    float2v l2 = {l_run * f, 0.f}, q2 = {lq_run * f, 0.f};
+    m_w = m_new;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      l2 = l2 + float2v{ev[g * 4 + 0], ev[g * 4 + 1]} + float2v{ev[g * 4 + 2], ev[g * 4 + 3]};
+      q2 = q2 + __builtin_amdgcn_cvt_pk_f32_fp8(pk[g], false) + __builtin_amdgcn_cvt_pk_f32_fp8(pk[g], true);
+    }
+    l_run = l2[0] + l2[1];
+    lq_run = q2[0] + q2[1];
+  }
 }
 
 template <int FMT>
@@ -663,13 +658,13 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
         r.pf = 0;
       };
       for (int pass = 0; pass < 2; ++pass) {
-        float m_w = kNegRef;
+        float l_run = 0.f, lq_run = 0.f, m_w = kNegRef;
         RopeRegs rA, rB;
         if (pass == 1) load_window(0);
         load_rope(rA, 0);
         load_rope(rB, n > 1 ? 1 : 0);
         if constexpr (FMT == 0)
-          scale_prep(scratch, rA.ks, tile_b * kPage + 32 * W, li, L);   // page 0 -> buffer 0 (every wave's reads of the previous request / pass are behind its E0 barrier)
+          scale_prep(scratch, rA.ks, tile_b * kPage + 32 * W, li, L);   // page 0 -> parity 0 (this wave's reads of the previous request are done)
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // R0: every wave is done with the LDS of the previous request / pass
@@ -690,13 +685,13 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           const int tok0w = (tile_b + i) * kPage + 32 * W;
           const bool need_mask = (tile_b + i) * kPage + kPage > L_min;
           if constexpr (FMT == 1)
-            qk_step1(m_w, lc, lane, qn, qr8, qs, rr, rope_next,
+            qk_step1(l_run, lq_run, m_w, lc, lane, qn, qr8, qs, rr, rope_next,
                      smem + kOffRing + (i & 3) * kSlotBytes + W * (32 * kDN),
                      smem + kOffPbuf + (i & 1) * kPbufPerParity + (rt * 2 + W) * (64 * 16),
                      reinterpret_cast<float*>(smem + kOffRef + (i & 1) * kRefPerParity) + (rt * 2 + W) * 32, tok0w, L_row, need_mask);
           else
-          qk_step(m_w, lc, lane, qn, qr_lds, qs, rr, rn.ks, rope_next, scale_next, pf_next, pf_acc,
-                  smem + kOffRing + (i & 3) * kSlotBytes + W * (32 * kDN), scratch + (i % 3) * 96, scratch + ((i + 1) % 3) * 96,
+          qk_step(l_run, lq_run, m_w, lc, lane, qn, qr_lds, qs, rr, rn.ks, rope_next, scale_next, pf_next, pf_acc,
+                  smem + kOffRing + (i & 3) * kSlotBytes + W * (32 * kDN), scratch + (i & 1) * 96, scratch + ((i + 1) & 1) * 96,
                   smem + kOffPbuf + (i & 1) * kPbufPerParity + (rt * 2 + W) * (64 * 16),
                   reinterpret_cast<float*>(smem + kOffRef + (i & 1) * kRefPerParity) + (rt * 2 + W) * 32, tok0w, L, L_row,
                   need_mask FL_T_ARGS);
@@ -718,10 +713,16 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
 #if FL_Y_MID_BARRIER
         __builtin_amdgcn_s_barrier();   // M_n
 #endif
-        // final reference of this wave's blocks -> LDS (redo preset; the normaliser itself is summed by the PV waves)
+        // normalisers of this wave's blocks -> LDS for the PV waves' epilogue
         {
+          const float l_tot = l_run + __shfl_xor(l_run, 32);
+          const float lq_tot = lq_run + __shfl_xor(lq_run, 32);
           float* lm = reinterpret_cast<float*>(smem + kOffLm) + (rt * 2 + W) * 96;
-          if (lh == 0) lm[64 + li] = m_w;   // final block reference: the redo pass presets the O reference with it
+          if (lh == 0) {
+            lm[li] = l_tot;
+            lm[32 + li] = lq_tot;
+            lm[64 + li] = m_w;
+          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // E0
@@ -774,8 +775,6 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
 
     v16f o[8];
     float m_o = kNegRef;
-    // normaliser of the rounded weights in the units of m_o: one LDS float per lane (this lane's token halves; see pv_step)
-    float* lq_lds = reinterpret_cast<float*>(smem + kOffLm) + (rt * 2 + W) * 96;
     float mo_preset = kNegRef;
     // pass 0 fixes the O reference at each row's first valid page; pass 1 runs only if some block reference outran it
     // by more than kMaxUp (pv_step), with the reference preset to the final one
@@ -785,7 +784,6 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
       m_o = mo_preset;
-      lq_lds[lane] = 0.f;   // (own slot; the QK waves only write floats 64.. of these rows, after the page loop)
       int redo = 0;
       if (pass == 1) load_window(0);
 
@@ -811,11 +809,10 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const uint8_t* sn = HAS_DMA ? src_of(i + 2) : nullptr;                                                             \
     uint8_t* dst = ring(i + 2) + w4 * (kPiecesPerWave * 1024);                                                         \
     if (HAS_PREV) {                                                                                                    \
-      const float* ikb = reinterpret_cast<const float*>(smem + kOffScratch + rt * kScratchPerWave) + ((i - 1) % 3) * 96 + 64; \
-      pv_step<HAS_DMA, FMT>(o, m_o, lq_lds, redo, lc, lane, ring(i - 1) + W * 256,                                           \
+      pv_step<HAS_DMA, FMT>(o, m_o, redo, lc, lane, ring(i - 1) + W * 256,                                                  \
                        smem + kOffPbuf + ((i - 1) & 1) * kPbufPerParity + rt * (2 * 64 * 16),                          \
-                       reinterpret_cast<const float*>(smem + kOffRef + ((i - 1) & 1) * kRefPerParity) + rt * 64, ikb,  \
-                       ikb + 2 * (kScratchPerWave / 4), sn, dst FL_T_ARGS);                                            \
+                       reinterpret_cast<const float*>(smem + kOffRef + ((i - 1) & 1) * kRefPerParity) + rt * 64, sn,   \
+                       dst FL_T_ARGS);                                                                                 \
     } else {                                                                                                           \
       if (HAS_DMA) {                                                                                                   \
         _Pragma("unroll") for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s(sn, dn_off<FMT>(lc, k), dst + k * 1024);      \
@@ -851,16 +848,15 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     }
 
     // ---- per-request epilogue: merge the normalisers of the two blocks, normalise, store this wave's d half ----
-    // the two lane halves of a row hold the two token halves of every block
-    const float lq = lq_lds[li] + lq_lds[32 + li];
+    const float mA = lm[64 + li], mB = lm[96 + 64 + li];
+    const float fA = __builtin_amdgcn_exp2f(mA - m_o), fB = __builtin_amdgcn_exp2f(mB - m_o);   // <= 2^kMaxUp
+    const float l = lm[li] * fA + lm[96 + li] * fB;
+    const float lq = lm[32 + li] * fA + lm[96 + 32 + li] * fB;
     // (FMT 1: V = fp8 x descale_k, one device scalar for the whole cache)
     const float inv = (lq > 0.f ? 1.f / lq : 0.f) * (FMT == 1 ? (p.descale_k ? *p.descale_k : 1.f) : 1.f);
-    // LSE of the ROUNDED weights (round 3: the unrounded second normaliser is gone; flashmla_backend.py:208-224 discards the
-    // LSE, and split-KV partials — normalised by lq — have to be combined with lq-based weights anyway).  It differs from the
-    // exact LSE by log of a weighted mean of the e4m3 rounding factors: <= log(1 + 2^-4) = 0.061 for a single token,
-    // shrinking as 1 / sqrt(N_eff); both slots of a split partial carry it.
+    const float lse_nat = l > 0.f ? (__builtin_amdgcn_logf(l) + m_o - kPShift) * 0.6931471805599453f : -INFINITY;
+    // split-KV partials are normalised by lq, so they are COMBINED with lq-based weights; the exact LSE travels along
     const float lseq_nat = lq > 0.f ? (__builtin_amdgcn_logf(lq) + m_o - kPShift) * 0.6931471805599453f : -INFINITY;
-    const float lse_nat = lseq_nat;
     const int slot_idx = split_base + split_idx;
     if (row_ok && lh == 0 && W == 0) {
       if (is_split) {   // (agent-scope stores: read by whichever part merges the request, see the merge below)

@@ -146,19 +146,11 @@ def run_decode(fm, c, H, s_q=1, causal=True, emulate=True):
             c["k_rope"].view(pages, 64, 1, 64), c["block_table"], c["cache_seqlens"], SCALE, causal)
     ref, rlse = mla_ref.mla_decode_fp8_per_token(*args)
     if emulate:
-        emu, else_ = mla_ref.mla_decode_fp8_per_token_emulated(*args)
+        emu, _ = mla_ref.mla_decode_fp8_per_token_emulated(*args)
         e = (o.cpu().double() - emu).abs()
         r = float(e.mean() / emu.abs().mean().clamp_min(1e-30))
         # the kernel must do exactly what its design says (fp32-vs-fp64 accumulation and rare 1-ulp P' flips only)
         assert r < 3e-3, ("vs bit-level statement of the kernel", r)
-        # ... including its LSE (of the rounded weights): a P' that flips by one e4m3 step moves a short row's sum by <= 2^-4 / N
-        # (the mappings for <= 32 query rows and the FLUENT_MLA_Y=0 ones still carry the exact second normaliser: either statement)
-        fin = torch.isfinite(else_)
-        assert torch.equal(torch.isfinite(lse.cpu()), fin)
-        if bool(fin.any()):
-            d_q = (lse.cpu().double()[fin] - else_[fin]).abs()
-            d_x = (lse.cpu().double()[fin] - rlse[fin]).abs()
-            assert float(torch.minimum(d_q, d_x).max()) < 2e-2 and (float(d_q.max()) < 2e-2 or float(d_x.max()) < 2e-2)
     return o.cpu(), lse.cpu(), ref, rlse, ns.cpu()
 
 
@@ -198,9 +190,7 @@ def _check(o, lse, ref, rlse, tag):
     fin = torch.isfinite(rlse)
     assert torch.equal(torch.isfinite(lse), fin), tag
     lerr = (lse.double()[fin] - rlse[fin]).abs()
-    # LSE of the e4m3-ROUNDED weights (the kernel's only normaliser since round 3) vs the exact one: every weight moves by a
-    # factor in [1 - 2^-4, 1 + 2^-4], so |d lse| <= log(1 + 2^-4) = 0.0606 (reached by a 1-token sequence), + fp32 score arithmetic
-    assert bool((lerr < 6.2e-2 + 1e-4 * rlse[fin].abs()).all()), (tag, float(lerr.max()))
+    assert bool((lerr < 2e-2 + 1e-4 * rlse[fin].abs()).all()), (tag, float(lerr.max()))   # fp32 score arithmetic
     return rel
 
 
