@@ -82,24 +82,31 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int wn = wave & 3, wm = wave >> 2;
+
+  // ---- PERSISTENT tile walk: the launch has one workgroup per CU (135 KiB of LDS: one fits); workgroup b takes the slots
+  //      b, b + grid, b + 2 grid, ... of the tile list.  Between two tiles of a workgroup nothing is torn down: no
+  //      dispatch gap, the LDS stays allocated, and group X's epilogue + next prologue run beside group Y's last M segment.
+  //      XCD-aware order (speed only): slot s runs on XCD s % 8 (grid % 8 == 0); within a round of 256 slots XCD x takes the
+  //      logical tiles [32x, 32x + 32) of the round (n fastest: the 2 x 16 tiles of a 512-row expert share their W and A
+  //      panels through ONE L2).  The last, partial round keeps the identity order. ----
+  const int n_tiles = p.n_tiles;
+  int gb = 0;   // stages issued by the tiles before this one (a multiple of 2): ring slot of stage hs = (gb + hs) & 3
+#pragma unroll 1
+  for (int slot = blockIdx.x; slot < p.total_blocks; slot += gridDim.x) {
 #ifdef FL_GEMM2_TIMING
   const unsigned long long t_entry = __builtin_readcyclecounter();
   const unsigned long long w_entry = wall_clock64();
 #endif
-
-  // ---- XCD-aware tile order (speed only): workgroup b runs on XCD b % 8; within a round of 256 workgroups XCD x takes
-  //      the logical tiles [32x, 32x + 32) of the round.  The last, partial round keeps the identity order. ----
-  const int n_tiles = p.n_tiles;
-  int lid = blockIdx.x;
+  int lid = slot;
   {
-    const int total = gridDim.x, round = lid >> 8;
-    if ((round + 1) * 256 <= total) lid = (round << 8) + ((lid & 7) << 5) + ((lid & 255) >> 3);
+    const int round = lid >> 8;
+    if ((round + 1) * 256 <= p.total_blocks) lid = (round << 8) + ((lid & 7) << 5) + ((lid & 255) >> 3);
   }
   const int nt = lid % n_tiles;
   const int mt = lid / n_tiles;
   int e = 0;
   long long row0 = 0, row_end = 0;
-  if (!locate_tile<BMB>(p, gmeta, mt, e, row0, row_end)) return;
+  if (!locate_tile<BMB>(p, gmeta, mt, e, row0, row_end)) continue;   // (surplus slot of the upper-bound tile count: workgroup-uniform)
   const int n0 = nt * BNB;
   const int KB = p.K / BK;
   const int NH = 2 * KB;
@@ -140,14 +147,14 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   // loop body, constant vmcnt counts.
   auto issue_piece = [&](const int hs, const int k) {
     const int hc = hs < NH ? hs : NH - 1;
-    uint8_t* s = smem + (hs & (kSlots - 1)) * kSlot + (2 * wave) * 1024;
+    uint8_t* s = smem + ((gb + hs) & (kSlots - 1)) * kSlot + (2 * wave) * 1024;
     if (k == 0) fl_dma16_s(uniform(w_base + (long long)hc * BKH), voff_w0, s);
     else if (k == 1) fl_dma16_s(uniform(w_base + (long long)hc * BKH), voff_w1, s + 1024);
     else if (k == 2) fl_dma16_s(uniform(a_base + (long long)hc * BKH), voff_a0, s + kWHalf);
     else if (k == 3) fl_dma16_s(uniform(a_base + (long long)hc * BKH), voff_a1, s + kWHalf + 1024);
     else {
       const int kb = hs >> 1, kc = kb < KB ? kb : KB - 1;
-      fl_dma4(as_src + (long long)kc * p.as_stride_k, smem + kSlots * kSlot + (kb & 1) * kAsSlot + wave * 256);
+      fl_dma4(as_src + (long long)kc * p.as_stride_k, smem + kSlots * kSlot + (((gb >> 1) + kb) & 1) * kAsSlot + wave * 256);
     }
   };
   auto issue = [&](const int hs, const bool even) {
@@ -179,8 +186,8 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   //      four L waves of an interval would queue 18 pieces behind each other at the CU's vector-memory path (measured:
   //      L segments of ~810 cycles, the slowest wave of a group sets the interval) — the refill rides behind the MFMAs ----
   auto seg_load = [&](const int h, const bool even, const bool first_kb) {
-    const uint8_t* sw = smem + (h & (kSlots - 1)) * kSlot + (64 * wn) * BKH;
-    const uint8_t* sa = smem + (h & (kSlots - 1)) * kSlot + kWHalf + (128 * wm) * BKH;
+    const uint8_t* sw = smem + ((gb + h) & (kSlots - 1)) * kSlot + (64 * wn) * BKH;
+    const uint8_t* sa = smem + ((gb + h) & (kSlots - 1)) * kSlot + kWHalf + (128 * wm) * BKH;
     wa[0] = ld8(sw);
     wa[1] = ld8(sw + 32 * BKH);
 #pragma unroll
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     if (even) {
       const int kb = h >> 1;
       const float ws = wsrow[kb];
-      const float* sas = reinterpret_cast<const float*>(smem + kSlots * kSlot + (kb & 1) * kAsSlot) + 64 * (4 * wm) + li;
+      const float* sas = reinterpret_cast<const float*>(smem + kSlots * kSlot + (((gb >> 1) + kb) & 1) * kAsSlot) + 64 * (4 * wm) + li;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float s = sas[64 * j] * ws;
@@ -351,39 +358,62 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   // ---- epilogue: D^T[n, m] -> out[m, n] bf16; lane (m = token li of block j, half lh) holds n = 8g + 4lh + (0..3) ----
   // (the last MFMAs are still in the pipe: a 16-pass XDL write needs 18 wait states before a VALU read)
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[0][1]), "+v"(acc[1][1]));
+  // Through LDS: a lane holds ONE token row, 4 weight columns at a time — stored directly, every store instruction touches
+  // 32 rows x 16 B (measured: 18-20 k cycles per tile, as long as five k blocks; the epilogue of a K = 2048 tile was 27 % of
+  // its time).  The ring is idle here (every wave's operand reads are behind the last barrier this wave passed, and the next
+  // tile's stages 0..2 go to slots 0..2): each wave transposes one 32-token block at a time through 4 KiB of slot 3
+  // ([32 rows][128 B], 16-B chunk c of row r at position c ^ (r & 7): conflict-free both ways) and stores 128-B row
+  // segments, 8 rows per instruction.
+  {
+    // (slot of the LAST stage: the three stages in flight past the end of the tile — re-fetches of the last stage today, the
+    //  next tile's first stages once the prefetch crosses tiles — go to the other three; the next tile's stage 3 is issued
+    //  only behind two more workgroup barriers, which the other group passes after ITS epilogue)
+    uint8_t* stg = smem + ((gb + NH - 1) & (kSlots - 1)) * kSlot + (wave & 3) * 4096;
+    const int rr = lane >> 3, rc = lane & 7;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const long long m = row0 + 128 * wm + 32 * j + li;
-    const float cm = cmant[j];
-    if (m < row_end) {
-      uint16_t* orow = p.out + m * p.N;
+    for (int j = 0; j < 4; ++j) {
+      const float cm = cmant[j];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n0 + 64 * wn + 32 * i + 8 * g + 4 * lh;
-          if (n + 3 < p.N) {
-            *reinterpret_cast<uint2*>(orow + n) = make_uint2(fl_pack_bf16(acc[i][j][4 * g + 0] * cm, acc[i][j][4 * g + 1] * cm),
-                                                            fl_pack_bf16(acc[i][j][4 * g + 2] * cm, acc[i][j][4 * g + 3] * cm));
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<uint2*>(stg + li * 128 + (((4 * i + g) ^ (li & 7)) << 4) + 8 * lh) =
+              make_uint2(fl_pack_bf16(acc[i][j][4 * g + 0] * cm, acc[i][j][4 * g + 1] * cm),
+                         fl_pack_bf16(acc[i][j][4 * g + 2] * cm, acc[i][j][4 * g + 3] * cm));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-private buffer: the wave's own writes, in order)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = 8 * k + rr;
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + r * 128 + ((rc ^ (r & 7)) << 4));
+        const long long m = row0 + 128 * wm + 32 * j + r;
+        const int n = n0 + 64 * wn + 8 * rc;
+        if (m < row_end) {
+          uint16_t* orow = p.out + m * p.N;
+          if (n + 8 <= p.N) {
+            *reinterpret_cast<uint4*>(orow + n) = v;
           } else {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-              if (n + x < p.N) orow[n + x] = fl_f32_to_bf16(acc[i][j][4 * g + x] * cm);
+            for (int x = 0; x < 8; ++x)
+              if (n + x < p.N) orow[n + x] = (uint16_t)(w[x >> 1] >> (16 * (x & 1)));
           }
         }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the buffer
     }
   }
 #ifdef FL_GEMM2_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (g_g2dbg != nullptr && lane == 0 && blockIdx.x < 8192) {
-    unsigned long long* d = g_g2dbg + ((long long)blockIdx.x * 8 + wave) * 8;
+  if (g_g2dbg != nullptr && lane == 0 && slot < 8192) {
+    unsigned long long* d = g_g2dbg + ((long long)slot * 8 + wave) * 8;
     d[0] = gt[0]; d[1] = gt[1]; d[2] = gt[2]; d[3] = gt[3]; d[4] = t_loop_end - g0;
     d[5] = g0 - t_entry;                                   // tile lookup + address set-up
     d[6] = __builtin_readcyclecounter() - t_loop_end;      // epilogue incl. the wait for its stores
     d[7] = w_entry;                                        // wall clock (100 MHz) at entry: workgroup start times
   }
 #endif
+  gb += NH;
+  }   // persistent tile walk
 }
 
 }  // namespace
@@ -407,7 +437,18 @@ int fl_gemm_launch_big2(const GemmParams& p_in, const void* A, const float* As, 
   FL_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "fl_grouped_gemm_fp8: grid too large");
   FL_CHECK_ARG(p.N < (1 << 24) && p.K < (1 << 24) && (long long)p.N * p.K < (1ll << 32),
                "fl_grouped_gemm_fp8: N*K too large for the 256x256 tile");
-  grouped_gemm_fp8_big2_kernel<<<dim3((unsigned)blocks), dim3(512), 0, stream>>>(p, (const uint8_t*)A, As, (const uint8_t*)W, Ws,
+  p.total_blocks = (int)blocks;
+  // one workgroup per CU walks the tile list (FLUENT_GEMM_PERSIST=0: one workgroup per tile, for A/B runs)
+  static const bool persist = [] {
+    const char* e = getenv("FLUENT_GEMM_PERSIST");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  long long grid = blocks;
+  if (persist) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && fl_device_cu_count(dev, &cus) == FL_OK && cus > 0 && grid > cus) grid = cus;
+  }
+  grouped_gemm_fp8_big2_kernel<<<dim3((unsigned)grid), dim3(512), 0, stream>>>(p, (const uint8_t*)A, As, (const uint8_t*)W, Ws,
                                                                                 group_meta);
   FL_CHECK_LAUNCH("grouped_gemm_fp8_big2_kernel");
   return FL_OK;

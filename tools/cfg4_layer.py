@@ -52,7 +52,7 @@ def build(dev, world, rank, group, layers, seq=SEQ, bs=BS, seed=0):
 
     wl = bench.build_workload(dev, layers, bs, seq, h, seed=seed + 3)      # same requests on every rank (TP): same seed
     meta, ns = fm.get_mla_metadata(wl["seqlens"], h, 1)
-    _, ws_tp = comm.trtllm_create_ipc_workspace_for_all_reduce_fusion(rank, world, bs, HID, group=group)
+    h_tp, ws_tp = comm.trtllm_create_ipc_workspace_for_all_reduce_fusion(rank, world, bs, HID, group=group)
     _, ws_one = comm.trtllm_create_ipc_workspace_for_all_reduce_fusion(0, 1, bs, HID)        # the exchange-free norm
     W = []
     for _ in range(layers):
@@ -123,7 +123,9 @@ def build(dev, world, rank, group, layers, seq=SEQ, bs=BS, seed=0):
         "ep_combine": (world - 1) * (a2a.cap * HID * 2 + a2a.cap * TOPK * 4)}
     info = dict(bs=bs, seq=seq, heads_per_rank=h, experts_per_rank=el, tokens_per_rank=t_loc, routed_row_bound=rows,
                 ep_slab_rows_per_peer=a2a.cap, kv_bytes_per_layer=kv_bytes, weight_bytes_per_layer=w_bytes,
-                xgmi_send_bytes_per_layer=xgmi)
+                xgmi_send_bytes_per_layer=xgmi,
+                comm_route={"allgather / reducescatter (<= 1024 tokens)": "one-shot peer-mapped kernel" if getattr(h_tp[0], "oneshot", None) is not None
+                            else "RCCL collective + fused kernel", "ep_dispatch / ep_combine": "RCCL all_to_all_single"})
     # everything a checker needs to recompute the layer from its inputs (tests/test_cfg4_gpu.py); not used by the bench
     info["_state"] = dict(W=W, B=B, wl=wl, hid_loc=hid_loc, attn_o=attn_o, meta=meta, ns=ns, res_in=B["res"].clone())
     return step, info
