@@ -60,6 +60,13 @@ __device__ __forceinline__ void mfma_acc(v16f& acc, const v8i a, const v8i b, co
 #ifndef FL_GEMM2_PKMUL
 #define FL_GEMM2_PKMUL 0
 #endif
+#ifndef FL_GEMM2_DMA_LODD
+#define FL_GEMM2_DMA_LODD 0   // experiment: the pieces of stage h + 3 for EVEN h are issued in the (light) L segment of step h + 1
+                              // instead of behind the MFMAs of step h, whose M segment also carries 64 rescale multiplies
+#endif
+#ifndef FL_GEMM2_YPRIO
+#define FL_GEMM2_YPRIO 0      // experiment: static priority 1 for group Y (waves 4-7: the younger half loses the arbitration)
+#endif
 #ifndef FL_GEMM2_PRIO
 #define FL_GEMM2_PRIO 0   // measured (profiles/r03_gemm_big2_variants_ab.txt): +2 % without the priority flips
 #endif
@@ -186,6 +193,10 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   //      four L waves of an interval would queue 18 pieces behind each other at the CU's vector-memory path (measured:
   //      L segments of ~810 cycles, the slowest wave of a group sets the interval) — the refill rides behind the MFMAs ----
   auto seg_load = [&](const int h, const bool even, const bool first_kb) {
+    if (FL_GEMM2_DMA_LODD && !even) {   // stage (h - 1) + 3 of the previous, even step
+#pragma unroll
+      for (int k = 0; k < 4; ++k) issue_piece(h + 2, k);
+    }
     const uint8_t* sw = smem + ((gb + h) & (kSlots - 1)) * kSlot + (64 * wn) * BKH;
     const uint8_t* sa = smem + ((gb + h) & (kSlots - 1)) * kSlot + kWHalf + (128 * wm) * BKH;
     wa[0] = ld8(sw);
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
       for (int t = 0; t < 8; ++t) {
         const int j = (2 + (t >> 1)) & 3, i = t & 1;
         mfma_zero(acc[i][j], wa[i], tb[j], e8[j]);
-        if (t >= 4) issue_piece(h + 3, t - 4);
+        if (t >= 4 && !FL_GEMM2_DMA_LODD) issue_piece(h + 3, t - 4);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
       for (int t = 0; t < 4; ++t) {
         const int j = t >> 1, i = t & 1;
         mfma_acc(acc[i][j], wa[i], tb[j], e8[j]);
-        if (even) issue_piece(h + 3, t);
+        if (even) { if (!FL_GEMM2_DMA_LODD) issue_piece(h + 3, t); }
         else if (t == 0) issue_piece(h + 3, 4);   // (h odd: stage h + 3 is even — it carries the scales)
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -300,7 +311,9 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     GT(3);
     seg_mma(h, true, first);
     GT(1);
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    // (FL_GEMM2_DMA_LODD: stage h + 3 has not been issued yet — it goes out in the L segment below: only stage h + 2 stays in flight)
+    if (FL_GEMM2_DMA_LODD) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     GT(2);
     G2_BARRIER();
     GT(3);
@@ -344,6 +357,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     GT(1);
     G2_BARRIER();   // (group Y's last M segment starts here)
   } else {         // ---------------- group Y: the same stream, one segment later ----------------
+    if (FL_GEMM2_YPRIO) __builtin_amdgcn_s_setprio(1);
     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     G2_BARRIER();
     kblock_y(0, true);
@@ -368,7 +382,9 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     // (slot of the LAST stage: the three stages in flight past the end of the tile — re-fetches of the last stage today, the
     //  next tile's first stages once the prefetch crosses tiles — go to the other three; the next tile's stage 3 is issued
     //  only behind two more workgroup barriers, which the other group passes after ITS epilogue)
-    uint8_t* stg = smem + ((gb + NH - 1) & (kSlots - 1)) * kSlot + (wave & 3) * 4096;
+    // (every wave has its OWN 4 KiB: the two groups' epilogues overlap in time — group Y's starts one M segment, ~700 cycles,
+    //  after group X's)
+    uint8_t* stg = smem + ((gb + NH - 1) & (kSlots - 1)) * kSlot + wave * 4096;
     const int rr = lane >> 3, rc = lane & 7;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
