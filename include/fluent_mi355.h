@@ -319,6 +319,15 @@ int fl_ep_gather(const void* input_tensor /*bf16 [M, H]*/, int64_t in_stride, in
                  int64_t idx_stride, int64_t num_tokens, int top_k, int hidden, void* output_tensor /*bf16 [T, H]*/,
                  int64_t out_stride, fl_stream_t stream);
 
+/* ---- B1: the small dense bf16 GEMMs between the big kernels — weight absorption
+ * torch.bmm(q_nope.transpose(0,1), w_kc, out=Q[..., :512].transpose(0,1)) / torch.bmm(attn_output.transpose(0,1), w_vc)
+ * (srt/models/deepseek_v2.py:840,886; both weights are stored k-contiguous, :1632-1633) and the router GEMM
+ * flashinfer.dsv3_router_gemm(hidden, weight, out_dtype) (:177-179).  C[b,m,n] = sum_k A[b,m,k] * B[b,n,k]: bf16 operands
+ * contiguous in k, strides in elements, fp32 accumulation, C bf16 (RNE) or f32; N % 32 == 0, K % 16 == 0. ---- */
+int fl_bmm_bf16_nt(const void* A, const void* B, void* C, int batch, int64_t M, int N, int K, int64_t a_stride_b,
+                   int64_t a_stride_m, int64_t b_stride_b, int64_t b_stride_n, int64_t c_stride_b, int64_t c_stride_m,
+                   int out_is_f32, fl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,18 +17,16 @@ from . import activation, comm, quantization  # noqa: F401
 import torch as _torch
 
 
-def dsv3_router_gemm(hidden_states, weight, out_dtype=_torch.float32):
-    """models/deepseek_v2.py:46,177-179 imports this name unconditionally and calls it only behind `is_sm90_supported()`;
-    on MI355X MoEGate.forward takes its `F.linear` branch.  Kept importable and correct: router logits
-    hidden [T, K] x weight [E, K]^T as ONE plain library GEMM (rocBLAS / hipBLASLt through torch), result in `out_dtype`."""
-    return _torch.nn.functional.linear(hidden_states, weight, None).to(out_dtype)
+from fluent_mi355.bmm import dsv3_router_gemm  # noqa: F401,E402  (hand-written bf16 MFMA GEMM, csrc/bmm_bf16.hip)
 
 
 def dsv3_fused_a_gemm(hidden_states, weight_t):
     """models/deepseek_v2.py:46,785-793: the <= 16-token min-latency q_a/kv_a projection, behind
-    `use_min_latency_fused_a_gemm` (an sm90 switch).  Kept importable and correct as a plain library GEMM:
-    hidden [T, K] x weight_t [K, N]."""
-    return _torch.matmul(hidden_states, weight_t)
+    `use_min_latency_fused_a_gemm` (an sm90 switch): hidden [T, K] x weight_t [K, N] with weight_t k-contiguous (the
+    transposed view of the [N, K] parameter, as the call site passes it) -> the same hand-written MFMA kernel."""
+    from fluent_mi355.bmm import bmm as _bmm
+
+    return _bmm(hidden_states.unsqueeze(0), weight_t.unsqueeze(0))[0]
 
 
 def merge_state(v_a, s_a, v_b, s_b):
