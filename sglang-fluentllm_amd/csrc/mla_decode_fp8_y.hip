@@ -297,20 +297,35 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
     tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
   }
   FL_T(7);   // MFMA drain + scaling + max
-  const float m_new = tmax > m_w ? ceilf(tmax) + kRefHeadroom : m_w;
-  const float moff = kPShift - m_new;
+#ifndef FL_Y_LAG_REF
+#define FL_Y_LAG_REF 1   // the exponentials are taken against the reference CARRIED IN (m_w), which does not depend on this
+                         // block's maximum: the 16 exp2 / 8 e4m3 conversions are independent of the max chain and the
+                         // lane-half exchange above and fill their latencies.  The reference moves only when a block's
+                         // maximum exceeds it (m_new != m_w <=> tmax > m_w: after the first page a rare event — the reference
+                         // sits 2..3 binades above the running maximum); then the WAVE repeats the exponentials with the new
+                         // reference.  Same P' bytes, same references, same sums as the in-order form (FL_Y_LAG_REF=0).
+#endif
+  float m_new = tmax > m_w ? ceilf(tmax) + kRefHeadroom : m_w;
   float ev[16];
   int pk[4];
+  auto expo = [&](const float moff) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float2v a01 = float2v{acc[g * 4 + 0], acc[g * 4 + 1]} + float2v{moff, moff};
-    const float2v a23 = float2v{acc[g * 4 + 2], acc[g * 4 + 3]} + float2v{moff, moff};
-    ev[g * 4 + 0] = __builtin_amdgcn_exp2f(a01[0]);
-    ev[g * 4 + 1] = __builtin_amdgcn_exp2f(a01[1]);
-    ev[g * 4 + 2] = __builtin_amdgcn_exp2f(a23[0]);
-    ev[g * 4 + 3] = __builtin_amdgcn_exp2f(a23[1]);
-    const int v = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 0], ev[g * 4 + 1], 0, false);
-    pk[g] = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 2], ev[g * 4 + 3], v, true);
+    for (int g = 0; g < 4; ++g) {
+      const float2v a01 = float2v{acc[g * 4 + 0], acc[g * 4 + 1]} + float2v{moff, moff};
+      const float2v a23 = float2v{acc[g * 4 + 2], acc[g * 4 + 3]} + float2v{moff, moff};
+      ev[g * 4 + 0] = __builtin_amdgcn_exp2f(a01[0]);
+      ev[g * 4 + 1] = __builtin_amdgcn_exp2f(a01[1]);
+      ev[g * 4 + 2] = __builtin_amdgcn_exp2f(a23[0]);
+      ev[g * 4 + 3] = __builtin_amdgcn_exp2f(a23[1]);
+      const int v = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 0], ev[g * 4 + 1], 0, false);
+      pk[g] = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 2], ev[g * 4 + 3], v, true);
+    }
+  };
+  if (FL_Y_LAG_REF) {
+    expo(kPShift - m_w);                 // (first block of a row: m_w = kNegRef, garbage — always repeated below)
+    if (__any(m_new != m_w)) expo(kPShift - m_new);
+  } else {
+    expo(kPShift - m_new);
   }
   // publish P' (16 B per lane) and the block reference for the PV waves of this row tile
   *reinterpret_cast<uint4*>(pbuf_w + lane * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
