@@ -377,6 +377,67 @@ def gemm_roofline(dev):
     return res
 
 
+def dense_roofline(dev, T=256):
+    """G4 — the dense block-fp8 decode projections (deep_gemm.gemm_fp8_fp8_bf16_nt behind Fp8LinearMethod,
+    layers/dense/gemms/fp8/deep_geem.py:14-102) at T tokens, weights not re-served from cache (8 distinct copies in one hipGraph),
+    and B1, the bf16 absorption bmm's / router GEMM.  `hbm_frac` = weight bytes / time / 8 TB/s.  At T = 256 these GEMMs sit AT the
+    fp8 ridge point of the chip (2 T = 512 flop per weight byte vs 5 PF / 8 TB/s = 625): both roofs bind, see DESIGN.md."""
+    import deep_gemm
+    from fluent_mi355.bmm import bmm
+    from fluent_mi355.gemm import per_token_group_quant_fp8
+
+    g = torch.Generator(device=dev).manual_seed(5)
+    res = {"tokens": T}
+
+    def graph_time(fn, copies, reps=10):
+        fn(0)
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn(0)
+        torch.cuda.current_stream().wait_stream(s)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for c in range(copies):
+                fn(c)
+        gr.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / (reps * copies)
+
+    for N, K in ((2176, 7168), (7168, 2048)):
+        Ws = [(torch.randint(0, 120, (N, K), device=dev, generator=g, dtype=torch.uint8).view(torch.float8_e4m3fn),
+               torch.rand((N + 127) // 128, K // 128, device=dev, generator=g) * 1e-2) for _ in range(8)]
+        x = torch.randn(T, K, device=dev, generator=g).to(torch.bfloat16)
+        xq, xs = per_token_group_quant_fp8(x, column_major_scales=True)
+        out = torch.empty(T, N, dtype=torch.bfloat16, device=dev)
+        t = graph_time(lambda c: deep_gemm.gemm_fp8_fp8_bf16_nt((xq, xs), Ws[c], out), 8)
+        res[f"fp8_{N}x{K}"] = {"us": round(t * 1e6, 1), "weight_GBs": round(N * K / t / 1e9, 1),
+                               "hbm_frac": round(N * K / t / 1e9 / HBM_PEAK_GBS, 3), "TFLOPs": round(2.0 * T * N * K / t / 1e12, 1)}
+        del Ws
+    Hh = 128
+    q = torch.randn(T, Hh, 192, device=dev, generator=g).to(torch.bfloat16)
+    wkc = (torch.randn(Hh, 512, 128, device=dev, generator=g) * 0.05).to(torch.bfloat16).transpose(1, 2)      # [H, 128, 512], k-contiguous
+    wvc = (torch.randn(Hh, 128, 512, device=dev, generator=g) * 0.05).to(torch.bfloat16).transpose(1, 2)      # [H, 512, 128]
+    Q = torch.empty(T, Hh, 576, dtype=torch.bfloat16, device=dev)
+    att = torch.randn(T, Hh, 512, device=dev, generator=g).to(torch.bfloat16)
+    xr = torch.randn(T, 7168, device=dev, generator=g).to(torch.bfloat16)
+    wr = (torch.randn(256, 7168, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    import flashinfer
+    for name, fn, wbytes in (("bmm_q_absorb_H128", lambda c: bmm(q[..., :128].transpose(0, 1), wkc, out=Q[..., :512].transpose(0, 1)), Hh * 128 * 512 * 2),
+                             ("bmm_v_absorb_H128", lambda c: bmm(att.transpose(0, 1), wvc), Hh * 128 * 512 * 2),
+                             ("router_gemm_256x7168", lambda c: flashinfer.dsv3_router_gemm(xr, wr, out_dtype=torch.float32), 256 * 7168 * 2)):
+        t = graph_time(fn, 4)
+        res[name] = {"us": round(t * 1e6, 1), "weight_GBs": round(wbytes / t / 1e9, 1)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -530,6 +591,10 @@ def main():
         variants = {"cfg2_ragged": k1_ragged_variant(dev)}
         torch.cuda.empty_cache()
         gemm = gemm_roofline(dev)
+        try:
+            gemm["dense"] = dense_roofline(dev)
+        except Exception as ex_:   # an add-on: never at the expense of the headline record
+            gemm["dense"] = {"error": f"{type(ex_).__name__}: {ex_}"[:200]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()
     # ---- N > 1: BASELINE config 4 (attention-TP + EP MoE decoder layers, every collective of the path inside the captured step)

@@ -322,6 +322,18 @@ def test_oneshot_allgather_and_dual_rmsnorm_world1_match_the_collective_route(mo
     vllm_ar.dispose(h)
 
 
+def test_oneshot_beside_mla_decode_on_a_second_stream():
+    """the one-shot fused all-reduce between two processes while EACH keeps a second stream busy with MLA decode launches that
+    occupy every CU (8 waves x 256 VGPRs, 160 KB of LDS per workgroup): the push workgroups queue behind K1 workgroups —
+    latency, never a timeout, sums bit-identical to the RCCL route's kernel"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "oneshot_two_procs.py"), "2", "k1"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("beside K1 OK") == 2, r.stdout[-2000:]
+
+
 def test_oneshot_lost_peer_poisons_outputs_and_raises():
     """A peer that never issues an operation: the waiting rank's launch ends after its time budget with NaN in every output
     row (never partial sums), the epoch is not advanced, the next launch call and check() raise, and the late rank fails

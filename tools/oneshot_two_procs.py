@@ -118,11 +118,65 @@ def lost_peer_worker(rank, world, port, T, H):
         raise SystemExit(1)
 
 
+def beside_k1_worker(rank, world, port, T, H):
+    """C6 / C5 on one stream beside K1 on another (LongCat's two-stream layer, models/longcat_flash.py:417-445).
+    K1 fills every CU's registers and LDS (8 waves x 256 VGPRs, 160 KB), so the one-shot kernel's push workgroups queue
+    behind K1 workgroups while the peer spins on their flags: that must cost latency, never a timeout or a wrong sum.  Each
+    rank keeps a stream busy with cfg2-shaped K1 launches and runs fused all-reduces / reduce-scatters on the main stream."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    sys.path.insert(0, ROOT)
+    import bench
+    import flash_mla_fp8 as fm
+    from fluent_mi355.oneshot import OneShotComm
+    from fluent_mi355.comm import HipNormOps
+    c = OneShotComm(rank, world, 64, H, timeout_s=30.0)
+    ops = HipNormOps()
+    wl = bench.build_workload(dev, 2, 64, 2048, 128, seed=3 + rank)
+    meta, ns = fm.get_mla_metadata(wl["seqlens"], 128, 1)
+    side = torch.cuda.Stream()
+    stop_after = 150
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(T, H, generator=g).to(torch.bfloat16) for _ in range(world)]
+    res = torch.randn(T, H, generator=g).to(torch.bfloat16).to(dev)
+    gamma = torch.rand(H, generator=g).to(torch.bfloat16).to(dev)
+    e_res, e_norm = torch.empty(T, H, dtype=torch.bfloat16, device=dev), torch.empty(T, H, dtype=torch.bfloat16, device=dev)
+    ops.add_rmsnorm(torch.stack(xs).to(dev), None, res, gamma, 1e-6, e_res, e_norm, None, None)
+    x = xs[rank].to(dev)
+    o_res, o_norm = torch.empty_like(e_res), torch.empty_like(e_norm)
+    torch.cuda.synchronize(); dist.barrier()
+    ok = True
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(side):
+        for i in range(stop_after):
+            bench.layer_call(fm, wl, i & 1, meta, ns)
+    e0.record()
+    for i in range(60):
+        c.allreduce_fused(x, res, gamma, 1e-6, o_res, o_norm)
+        if i % 10 == 9:
+            torch.cuda.current_stream().synchronize()
+            ok &= torch.equal(o_res, e_res) and torch.equal(o_norm, e_norm)
+    e1.record()
+    torch.cuda.synchronize()
+    c.check()
+    print(f"rank {rank}/{world}: beside K1 {'OK' if ok else 'MISMATCH'}; fused all-reduce {e0.elapsed_time(e1) / 60 * 1e3:.1f} us/op while a second "
+          f"stream runs bs=64 seq=2048 H=128 MLA decode launches (processes sharing one GPU)", flush=True)
+    dist.barrier()
+    c.close()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
 if __name__ == "__main__":
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     if len(sys.argv) > 2 and sys.argv[2] == "lostpeer":
         mp.spawn(lost_peer_worker, args=(2, port, 16, 2048), nprocs=2, join=True)
+    elif len(sys.argv) > 2 and sys.argv[2] == "k1":
+        mp.spawn(beside_k1_worker, args=(2, port, 48, 7168), nprocs=2, join=True)
     else:
         mp.spawn(worker, args=(world, port, 49 if world == 2 else 48, 7168, 5), nprocs=world, join=True)   # 49 rows over 2 ranks: 25 / 24
