@@ -298,12 +298,13 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
   }
   FL_T(7);   // MFMA drain + scaling + max
 #ifndef FL_Y_LAG_REF
-#define FL_Y_LAG_REF 1   // the exponentials are taken against the reference CARRIED IN (m_w), which does not depend on this
-                         // block's maximum: the 16 exp2 / 8 e4m3 conversions are independent of the max chain and the
-                         // lane-half exchange above and fill their latencies.  The reference moves only when a block's
-                         // maximum exceeds it (m_new != m_w <=> tmax > m_w: after the first page a rare event — the reference
-                         // sits 2..3 binades above the running maximum); then the WAVE repeats the exponentials with the new
-                         // reference.  Same P' bytes, same references, same sums as the in-order form (FL_Y_LAG_REF=0).
+#define FL_Y_LAG_REF 0   // experiment (round 3, measured SLOWER at cfg2: 131.6-134.8 vs 127.7-129.0 us per launch on one box; H = 16
+                         // and bs = 16 unchanged — profiles/r03_k1_lag_ref_ab.txt): the exponentials taken against the reference
+                         // CARRIED IN (m_w), which does not depend on this block's maximum, so that the 16 exp2 / 8 e4m3
+                         // conversions are independent of the max chain and the lane-half exchange; when a block's maximum
+                         // moves the reference (tmax > m_w: rare after the first page) the wave repeats them.  Same P' bytes,
+                         // references and sums as the in-order form.  The extra issue slots (the fast-path exponentials of the
+                         // first pages are thrown away, the vote + branch) cost more than the dependency stalls they fill.
 #endif
   float m_new = tmax > m_w ? ceilf(tmax) + kRefHeadroom : m_w;
   float ev[16];
