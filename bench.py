@@ -569,7 +569,7 @@ def main():
         traffic, traffic_src = None, None
         y_on = os.environ.get("FLUENT_MLA_Y") != "0"
         try:
-            traffic_src = "profiles/r02_pmc_traffic.json" if y_on else "profiles/r01_pmc_traffic.json"
+            traffic_src = "profiles/r03_pmc_traffic.json" if y_on else "profiles/r01_pmc_traffic.json"
             with open(os.path.join(ROOT, traffic_src)) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch"])
         except Exception:

@@ -67,6 +67,11 @@ __device__ __forceinline__ void mfma_acc(v16f& acc, const v8i a, const v8i b, co
 #ifndef FL_GEMM2_YPRIO
 #define FL_GEMM2_YPRIO 0      // experiment: static priority 1 for group Y (waves 4-7: the younger half loses the arbitration)
 #endif
+#ifndef FL_GEMM2_XTILE
+#define FL_GEMM2_XTILE 1      // the refill crosses tile boundaries (0: every tile starts with a cold three-stage prologue).  Measured
+                              // (profiles/r03_gemm_big2_xtile_ab.txt): w13 -0.4 %, w2 +1.4 % — the kernel is power-capped; kept for the
+                              // short-k shapes (w2: 16 k blocks per tile) and because this form allocates without scratch (the 0 form: 8 B)
+#endif
 #ifndef FL_GEMM2_PRIO
 #define FL_GEMM2_PRIO 0   // measured (profiles/r03_gemm_big2_variants_ab.txt): +2 % without the priority flips
 #endif
@@ -97,71 +102,103 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   //      logical tiles [32x, 32x + 32) of the round (n fastest: the 2 x 16 tiles of a 512-row expert share their W and A
   //      panels through ONE L2).  The last, partial round keeps the identity order. ----
   const int n_tiles = p.n_tiles;
+  const int KB = p.K / BK;
+  const int NH = 2 * KB;
   int gb = 0;   // stages issued by the tiles before this one (a multiple of 2): ring slot of stage hs = (gb + hs) & 3
+
+  // What the refill and the epilogue of a tile need.  LDS-DMA sources: a half-step stage = 32 pieces of 1 KiB (16 rows x
+  // 64 B): wave w issues W pieces 2w, 2w+1 and A pieces 2w, 2w+1.  Lane i of a piece lands at +16 i: row i >> 2, chunk
+  // POSITION i & 3, which holds source chunk (i & 3) ^ ((row >> 2) & 3) — the swizzle is on the source address, the LDS
+  // image is lane-linear (conflict-free ds_read_b128 below: a 16-lane read group covers all 16 bank slots of 16 B).
+  struct TileSrc {
+    const uint8_t* w_base;
+    const uint8_t* a_base;
+    const float* as_src;   // the block scales of token 32 wave + (lane & 31)
+    unsigned vw0, vw1, va0, va1;
+    int e, n0;
+    long long row0, row_end;
+  };
+  auto setup_tile = [&](const int slot, TileSrc& t) -> bool {
+    int lid = slot;
+    const int round = lid >> 8;
+    if ((round + 1) * 256 <= p.total_blocks) lid = (round << 8) + ((lid & 7) << 5) + ((lid & 255) >> 3);
+    const int nt = lid % n_tiles, mt = lid / n_tiles;
+    int e = 0;
+    long long row0 = 0, row_end = 0;
+    if (!locate_tile<BMB>(p, gmeta, mt, e, row0, row_end)) return false;   // (surplus slot of the upper-bound tile count: workgroup-uniform)
+    t.e = e; t.row0 = row0; t.row_end = row_end; t.n0 = nt * BNB;
+    t.w_base = gW + (long long)e * p.N * p.K;
+    t.a_base = gA + row0 * p.K;
+    const unsigned swz = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    const unsigned n_last = (unsigned)p.N - 1u;                    // rows beyond N: clamped, results discarded
+    const unsigned m_last = (unsigned)(row_end - row0 - 1);        // rows beyond the group: clamped, never stored
+    const unsigned r = (unsigned)(32 * wave + (lane >> 2));
+    unsigned n = (unsigned)t.n0 + r;
+    t.vw0 = __umul24(n < n_last ? n : n_last, (unsigned)p.K) + swz;
+    n += 16u;
+    t.vw1 = __umul24(n < n_last ? n : n_last, (unsigned)p.K) + swz;
+    t.va0 = __umul24(r < m_last ? r : m_last, (unsigned)p.K) + swz;
+    t.va1 = __umul24(r + 16u < m_last ? r + 16u : m_last, (unsigned)p.K) + swz;
+    long long m = row0 + 32 * wave + li;
+    m = m < row_end ? m : row_end - 1;
+    t.as_src = p.mode == kMasked ? gAs + (long long)e * p.as_stride_g + (m - (long long)e * p.rows_per_group) * p.as_stride_m
+                                 : gAs + m * p.as_stride_m;
+    return true;
+  };
+
+  // ---- PERSISTENT tile walk: the launch has one workgroup per CU (135 KiB of LDS: one fits); workgroup b takes the slots
+  //      b, b + grid, b + 2 grid, ... of the tile list.  Between two tiles of a workgroup nothing is torn down, and
+  //      (FL_GEMM2_XTILE) the refill runs ACROSS tiles: the three stages that are in flight past the end of a tile are the
+  //      next tile's stages 0..2, the barrier that ends the tile is the next tile's first, and the next tile's lookup
+  //      is done while its first stages fly.  XCD-aware order (speed only): slot s runs on XCD s % 8 (grid % 8 == 0); within
+  //      a round of 256 slots XCD x takes the logical tiles [32x, 32x + 32) of the round (n fastest: the 2 x 16 tiles of a
+  //      512-row expert share their W and A panels through ONE L2).  The last, partial round keeps the identity order. ----
+  int slot = blockIdx.x;
+  TileSrc cur;
+  {
+    bool found = false;
+    for (; slot < p.total_blocks; slot += gridDim.x)
+      if (setup_tile(slot, cur)) { found = true; break; }
+    if (!found) return;
+  }
+  bool carried = false;   // stages 0..2 of `cur` are already in flight and its first barrier has been passed
 #pragma unroll 1
-  for (int slot = blockIdx.x; slot < p.total_blocks; slot += gridDim.x) {
+  for (;;) {
 #ifdef FL_GEMM2_TIMING
   const unsigned long long t_entry = __builtin_readcyclecounter();
   const unsigned long long w_entry = wall_clock64();
 #endif
-  int lid = slot;
-  {
-    const int round = lid >> 8;
-    if ((round + 1) * 256 <= p.total_blocks) lid = (round << 8) + ((lid & 7) << 5) + ((lid & 255) >> 3);
-  }
-  const int nt = lid % n_tiles;
-  const int mt = lid / n_tiles;
-  int e = 0;
-  long long row0 = 0, row_end = 0;
-  if (!locate_tile<BMB>(p, gmeta, mt, e, row0, row_end)) continue;   // (surplus slot of the upper-bound tile count: workgroup-uniform)
-  const int n0 = nt * BNB;
-  const int KB = p.K / BK;
-  const int NH = 2 * KB;
+  TileSrc nxt = cur;
+  bool has_next = false;
+  int nslot = slot + gridDim.x;
+  for (; nslot < p.total_blocks; nslot += gridDim.x)
+    if (setup_tile(nslot, nxt)) { has_next = true; break; }
+  const bool xt = FL_GEMM2_XTILE && has_next;   // the stages past the end of this tile belong to `nxt`
+  const int e = cur.e, n0 = cur.n0;
+  const long long row0 = cur.row0, row_end = cur.row_end;
 
-  // ---- LDS-DMA sources.  A half-step stage = 32 pieces of 1 KiB (16 rows x 64 B): wave w issues W pieces 2w, 2w+1 and A
-  //      pieces 2w, 2w+1.  Lane i of a piece lands at +16 i: row i >> 2, chunk POSITION i & 3, which holds source chunk
-  //      (i & 3) ^ ((row >> 2) & 3) — the swizzle is on the source address, the LDS image is lane-linear (conflict-free
-  //      ds_read_b128 below: a 16-lane read group covers all 16 bank slots of 16 B) ----
-  const uint8_t* w_base = gW + (long long)e * p.N * p.K;
-  const uint8_t* a_base = gA + row0 * p.K;
-  const unsigned swz = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
-  const unsigned n_last = (unsigned)p.N - 1u;                    // rows beyond N: clamped, results discarded
-  const unsigned m_last = (unsigned)(row_end - row0 - 1);        // rows beyond the group: clamped, never stored
-  unsigned voff_w0, voff_w1, voff_a0, voff_a1;
-  {
-    const unsigned r = (unsigned)(32 * wave + (lane >> 2));
-    unsigned n = (unsigned)n0 + r;
-    voff_w0 = __umul24(n < n_last ? n : n_last, (unsigned)p.K) + swz;
-    n += 16u;
-    voff_w1 = __umul24(n < n_last ? n : n_last, (unsigned)p.K) + swz;
-    voff_a0 = __umul24(r < m_last ? r : m_last, (unsigned)p.K) + swz;
-    voff_a1 = __umul24(r + 16u < m_last ? r + 16u : m_last, (unsigned)p.K) + swz;
-  }
-  const float* as_src;   // the block scales of token 32 wave + (lane & 31)
-  {
-    long long m = row0 + 32 * wave + li;
-    m = m < row_end ? m : row_end - 1;
-    as_src = p.mode == kMasked ? gAs + (long long)e * p.as_stride_g + (m - (long long)e * p.rows_per_group) * p.as_stride_m
-                               : gAs + m * p.as_stride_m;
-  }
   auto uniform = [](const uint8_t* ptr) {   // (keeps the 64-bit base in an SGPR pair: the asm operand is "s")
     const unsigned long long v = (unsigned long long)ptr;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<const uint8_t*>(((unsigned long long)hi << 32) | lo);
   };
   // Piece k of this wave's share of stage hs: 0, 1 = W pieces, 2, 3 = A pieces, 4 = the token scales of k block hs / 2
-  // (even stages only).  A stage past the last one re-fetches the last (clamped source; its slot is idle by then): ONE
-  // loop body, constant vmcnt counts.
+  // (even stages only).  Stages NH .. NH+2 are the next tile's stages 0 .. 2 (or, without a next tile, re-fetches of the last
+  // stage into idle slots): ONE loop body, constant vmcnt counts.
   auto issue_piece = [&](const int hs, const int k) {
-    const int hc = hs < NH ? hs : NH - 1;
+    const bool nx = xt && hs >= NH;
+    const int hc = nx ? hs - NH : (hs < NH ? hs : NH - 1);
     uint8_t* s = smem + ((gb + hs) & (kSlots - 1)) * kSlot + (2 * wave) * 1024;
-    if (k == 0) fl_dma16_s(uniform(w_base + (long long)hc * BKH), voff_w0, s);
-    else if (k == 1) fl_dma16_s(uniform(w_base + (long long)hc * BKH), voff_w1, s + 1024);
-    else if (k == 2) fl_dma16_s(uniform(a_base + (long long)hc * BKH), voff_a0, s + kWHalf);
-    else if (k == 3) fl_dma16_s(uniform(a_base + (long long)hc * BKH), voff_a1, s + kWHalf + 1024);
+    const uint8_t* wb = nx ? nxt.w_base : cur.w_base;
+    const uint8_t* ab = nx ? nxt.a_base : cur.a_base;
+    if (k == 0) fl_dma16_s(uniform(wb + (long long)hc * BKH), nx ? nxt.vw0 : cur.vw0, s);
+    else if (k == 1) fl_dma16_s(uniform(wb + (long long)hc * BKH), nx ? nxt.vw1 : cur.vw1, s + 1024);
+    else if (k == 2) fl_dma16_s(uniform(ab + (long long)hc * BKH), nx ? nxt.va0 : cur.va0, s + kWHalf);
+    else if (k == 3) fl_dma16_s(uniform(ab + (long long)hc * BKH), nx ? nxt.va1 : cur.va1, s + kWHalf + 1024);
     else {
-      const int kb = hs >> 1, kc = kb < KB ? kb : KB - 1;
-      fl_dma4(as_src + (long long)kc * p.as_stride_k, smem + kSlots * kSlot + (((gb >> 1) + kb) & 1) * kAsSlot + wave * 256);
+      const int kb = hs >> 1, kc = nx ? hc >> 1 : (kb < KB ? kb : KB - 1);
+      fl_dma4((nx ? nxt.as_src : cur.as_src) + (long long)kc * p.as_stride_k,
+              smem + kSlots * kSlot + (((gb >> 1) + kb) & 1) * kAsSlot + wave * 256);
     }
   };
   auto issue = [&](const int hs, const bool even) {
@@ -291,19 +328,23 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   unsigned long long gl = __builtin_readcyclecounter();
   const unsigned long long g0 = gl;
 #endif
-  // ---- prologue: three half-step stages in flight ----
-  issue(0, true);
-  issue(1, false);
-  issue(2, true);
+  // ---- prologue: three half-step stages in flight (a carried tile's are: the previous tile issued them) ----
+  if (!carried) {
+    issue(0, true);
+    issue(1, false);
+    issue(2, true);
+  }
 
   // One k block of each group's stream.  `first` is a literal at both call sites (k block 0 is peeled off the loop: ONE body
   // variant inside the loop — a run-time branch around the MFMAs makes hipcc copy the accumulators at the join).
-  auto kblock_x = [&](const int kb, const bool first) __attribute__((always_inline)) {
+  auto kblock_x = [&](const int kb, const bool first, const bool skip_head) __attribute__((always_inline)) {
     const int h = 2 * kb;
     GT(1);
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // this wave's pieces of stage h (h + 1, h + 2 stay in flight)
-    GT(2);
-    G2_BARRIER();                                      // everyone's; slot h - 1 is free
+    if (!skip_head) {   // (carried tile: the wait + barrier that ended the previous tile were these)
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // this wave's pieces of stage h (h + 1, h + 2 stay in flight)
+      GT(2);
+      G2_BARRIER();                                      // everyone's; slot h - 1 is free
+    }
     GT(3);
     seg_load(h, true, first);
     GT(0);
@@ -351,15 +392,22 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     seg_mma(h + 1, false, false);
   };
   if (wm == 0) {   // ---------------- group X ----------------
-    kblock_x(0, true);
+    kblock_x(0, true, carried);
 #pragma unroll 1
-    for (int kb = 1; kb < KB; ++kb) kblock_x(kb, false);
+    for (int kb = 1; kb < KB; ++kb) kblock_x(kb, false, false);
     GT(1);
+    // the next tile's stage 0 (= stage NH: 9 younger pieces stay in flight) has landed before the barrier that ends this
+    // tile AND opens the next one.  The epilogue's stores come BEHIND this wait: stores may retire out of order with
+    // the loads, so a count taken after them could be met with a stage-0 piece still in flight; every later wait has
+    // at least one whole younger stage behind the one it waits for, which in-order load return makes sufficient
+    if (xt) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     G2_BARRIER();   // (group Y's last M segment starts here)
   } else {         // ---------------- group Y: the same stream, one segment later ----------------
     if (FL_GEMM2_YPRIO) __builtin_amdgcn_s_setprio(1);
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    G2_BARRIER();
+    if (!carried) {   // (carried: group Y's wait at the end of the previous tile's last L segment was for this stage)
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      G2_BARRIER();
+    }
     kblock_y(0, true);
 #pragma unroll 1
     for (int kb = 1; kb < KB; ++kb) kblock_y(kb, false);
@@ -429,6 +477,10 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   }
 #endif
   gb += NH;
+  if (!has_next) break;
+  cur = nxt;
+  slot = nslot;
+  carried = xt;
   }   // persistent tile walk
 }
 
