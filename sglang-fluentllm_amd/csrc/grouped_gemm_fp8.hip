@@ -278,15 +278,30 @@ __global__ __launch_bounds__(256, (MT == 4 && FL_MT4_STAGES > 2) ? 1 : 2) void g
   }
 }
 
-// out[m, n] = bf16(sum_s ws[s, m, n]); 4 consecutive columns per thread (N % 4 == 0)
+// out[m, n] = bf16(sum_s ws[s, m, n]) in split order; 4 consecutive columns per thread (N % 4 == 0).  The loads of up to 8 splits
+// go out together (a loop of dependent load -> add round trips is ~1 us per split).
+// Round 3, measured and NOT adopted (profiles/r03_dense_gemm_sweep.txt): reducing a tile inside the GEMM launch by its last-arriving
+// k split (arrival counters; hand-off by write-through stores + agent-scope loads, or by agent release / acquire fences) is SLOWER
+// than this second launch at every decode shape (18.9 / 37.8 vs 12.1 us at T = 32, [2176, 7168]): one workgroup per tile reads the
+// partials past its L2, against the whole chip here; a deeper LDS ring with one workgroup per CU for these launches: also slower.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, long long MN,
                                                             uint16_t* __restrict__ out) {
   const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= MN) return;
-  float4 a = *reinterpret_cast<const float4*>(ws + i);
-  for (int s = 1; s < ksplit; ++s) {
-    const float4 b = *reinterpret_cast<const float4*>(ws + (long long)s * MN + i);
-    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s0 = 0; s0 < ksplit; s0 += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int sj = s0 + j < ksplit ? s0 + j : ksplit - 1;   // (clamped: unconditional loads)
+      v[j] = *reinterpret_cast<const float4*>(ws + (long long)sj * MN + i);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (s0 + j < ksplit) {
+        if (s0 + j == 0) a = v[0];
+        else { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+      }
   }
   *reinterpret_cast<uint2*>(out + i) = make_uint2(fl_pack_bf16(a.x, a.y), fl_pack_bf16(a.z, a.w));
 }
