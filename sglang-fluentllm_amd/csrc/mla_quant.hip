@@ -12,6 +12,7 @@
 // for the 8 latent values, the compiler's correctly rounded `/` for the rope value) so the bytes are bit-identical to the
 // torch statement.
 #include "fl_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -125,6 +126,82 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void quant_qk_kernel(
   }
 }
 
+// The same launch with SIXTEEN lanes per row (round 3): a lane owns 2 x 16 consecutive latent elements (two 32-byte pieces of the
+// bf16 row, one 16-byte piece of fp8 output each) and 4 rope elements; a wave converts 4 rows per pass.  Per byte moved this is a
+// quarter of the instructions of the wave-per-row form (16-byte fp8 stores instead of 8, 8-byte rope accesses instead of 2), the
+// row maximum is 4 DPP steps inside the 16-lane row instead of 6 ds_bpermute round trips, and all loads of a wave's kPass x 4
+// rows are in flight before the first use.  Same per-element arithmetic (max is order-free, the division is fl_div8_to_fp8 on
+// groups of 8): bytes identical to quant_qk_kernel / the two separate calls (tests).
+template <int kPass>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void quant_qk16_kernel(
+    const uint16_t* __restrict__ key, int64_t n_k, const int32_t* __restrict__ indices, uint8_t* __restrict__ k_nope_out,
+    float* __restrict__ k_scale_out, uint16_t* __restrict__ k_rope_out, int64_t num_slots, const uint16_t* __restrict__ q,
+    int64_t n_q, uint8_t* __restrict__ q_nope_out, float* __restrict__ q_scale_out, uint16_t* __restrict__ q_rope_out) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 15, rl = lane >> 4;
+  const int64_t n = n_k + n_q;
+  const int64_t wave_row0 = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * (4 * kPass);
+  if (wave_row0 >= n) return;
+  u32x4 raw[kPass][4];
+  uint2 rope_raw[kPass];
+  int32_t dst_raw[kPass];
+#pragma unroll
+  for (int ps = 0; ps < kPass; ++ps) {
+    const int64_t row = wave_row0 + ps * 4 + rl < n ? wave_row0 + ps * 4 + rl : n - 1;   // (clamped loads; stores are predicated)
+    const bool is_k = row < n_k;
+    const uint16_t* p = is_k ? key + row * 576 : q + (row - n_k) * 576;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      raw[ps][2 * j] = *reinterpret_cast<const u32x4*>(p + 256 * j + sub * 16);
+      raw[ps][2 * j + 1] = *reinterpret_cast<const u32x4*>(p + 256 * j + sub * 16 + 8);
+    }
+    rope_raw[ps] = *reinterpret_cast<const uint2*>(p + 512 + sub * 4);
+    dst_raw[ps] = is_k ? indices[row] : 0;
+  }
+#pragma unroll
+  for (int ps = 0; ps < kPass; ++ps) {
+    const int64_t row = wave_row0 + ps * 4 + rl;
+    float v[4][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[g][2 * i] = __uint_as_float(raw[ps][g][i] << 16);
+        v[g][2 * i + 1] = __uint_as_float(raw[ps][g][i] & 0xffff0000u);
+        amax = fmaxf(amax, fmaxf(fabsf(v[g][2 * i]), fabsf(v[g][2 * i + 1])));
+      }
+    // maximum over the row's 16 lanes: rotations inside the DPP row (every lane ends with the row's value)
+    amax = fmaxf(amax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(amax), 0x128, 0xf, 0xf, false)));   // row_ror:8
+    amax = fmaxf(amax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(amax), 0x124, 0xf, 0xf, false)));   // row_ror:4
+    amax = fmaxf(amax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(amax), 0x122, 0xf, 0xf, false)));   // row_ror:2
+    amax = fmaxf(amax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(amax), 0x121, 0xf, 0xf, false)));   // row_ror:1
+    if (row >= n) continue;
+    const bool is_k = row < n_k;
+    const float scale = fmaxf(amax, 1e-26f) / FL_FP8_MAX;
+    int64_t dst = row - n_k;
+    if (is_k) {
+      dst = dst_raw[ps];
+      if (dst < 0 || dst >= num_slots) continue;  // never write out of the pool
+    }
+    uint8_t* nope_out = is_k ? k_nope_out : q_nope_out;
+    uint16_t* rope_out = is_k ? k_rope_out : q_rope_out;
+    float* scale_out = is_k ? k_scale_out : q_scale_out;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint2 w0 = fl_div8_to_fp8<false>(v[2 * j], scale);
+      const uint2 w1 = fl_div8_to_fp8<false>(v[2 * j + 1], scale);
+      *reinterpret_cast<uint4*>(nope_out + dst * 512 + 256 * j + sub * 16) = make_uint4(w0.x, w0.y, w1.x, w1.y);
+    }
+    const float r0 = __uint_as_float(rope_raw[ps].x << 16), r1 = __uint_as_float(rope_raw[ps].x & 0xffff0000u);
+    const float r2 = __uint_as_float(rope_raw[ps].y << 16), r3 = __uint_as_float(rope_raw[ps].y & 0xffff0000u);
+    *reinterpret_cast<uint2*>(rope_out + dst * 64 + sub * 4) =
+        make_uint2((uint32_t)fl_f32_to_bf16(r0 / scale) | ((uint32_t)fl_f32_to_bf16(r1 / scale) << 16),
+                   (uint32_t)fl_f32_to_bf16(r2 / scale) | ((uint32_t)fl_f32_to_bf16(r3 / scale) << 16));
+    if (sub == 0) scale_out[dst] = scale;
+  }
+}
+
 __global__ __launch_bounds__(64 * kWavesPerBlock) void dequant_gather_kernel(
     const uint8_t* __restrict__ nope, const uint16_t* __restrict__ rope, const float* __restrict__ scale,
     const int32_t* __restrict__ indices, int64_t n, int64_t num_slots, uint16_t* __restrict__ nope_out,
@@ -198,17 +275,25 @@ extern "C" int fl_mla_quant_q_store_k(const void* key, int64_t n_k, const int32_
   FL_CHECK_ARG(q_rows == 0 || (q && q_nope && q_scale && q_rope), "fl_mla_quant_q_store_k: null Q pointer");
   const int64_t n = n_k + q_rows;
   if (n == 0) return FL_OK;
-  if (n >= 8192) {
-    const int64_t blocks = (n + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock);
-    quant_qk_kernel<2><<<dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream>>>(
-        (const uint16_t*)key, n_k, indices, (uint8_t*)k_lora_cache, k_scale_cache, (uint16_t*)k_rope_cache, num_slots,
-        (const uint16_t*)q, q_rows, (uint8_t*)q_nope, q_scale, (uint16_t*)q_rope);
-  } else {
-    const int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
-    quant_qk_kernel<1><<<dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, (hipStream_t)stream>>>(
-        (const uint16_t*)key, n_k, indices, (uint8_t*)k_lora_cache, k_scale_cache, (uint16_t*)k_rope_cache, num_slots,
-        (const uint16_t*)q, q_rows, (uint8_t*)q_nope, q_scale, (uint16_t*)q_rope);
-  }
+  // Measured (MI355X, tools/time_quant.py, bs = 128 x H = 128 + 128 K rows = 29.5 MB moved): wave per row, 2 rows per wave 9.4-9.6 us;
+  // 4 rows per wave 11.0; 16 lanes per row 9.0 (3.3 TB/s), two passes per wave 10.6.  Decode-sized launches (bs 1 / 16: 3.0 / 3.6 us,
+  // launch-bound) stay on the wave-per-row form (16 lanes per row: 3.5 / 3.7 us).
+  static const int form_env = [] {   // experiment knob: 1 / 2 = wave per row with that many rows per wave, 16 = 16 lanes per row
+    const char* e = getenv("FLUENT_QK_FORM");
+    return e != nullptr ? atoi(e) : 0;
+  }();
+  const int form = form_env > 0 ? form_env : (n >= 8192 ? 16 : 1);
+#define FL_QK_ARGS                                                                                                                 \
+  (const uint16_t*)key, n_k, indices, (uint8_t*)k_lora_cache, k_scale_cache, (uint16_t*)k_rope_cache, num_slots, (const uint16_t*)q, \
+      q_rows, (uint8_t*)q_nope, q_scale, (uint16_t*)q_rope
+#define FL_LAUNCH_QK(KERNEL_, ROWS_)                                                                                              \
+  KERNEL_<<<dim3((unsigned)((n + ROWS_ * kWavesPerBlock - 1) / (ROWS_ * kWavesPerBlock))), dim3(64 * kWavesPerBlock), 0,            \
+            (hipStream_t)stream>>>(FL_QK_ARGS)
+  if (form == 16) FL_LAUNCH_QK(quant_qk16_kernel<1>, 4);
+  else if (form == 2) FL_LAUNCH_QK(quant_qk_kernel<2>, 2);
+  else FL_LAUNCH_QK(quant_qk_kernel<1>, 1);
+#undef FL_LAUNCH_QK
+#undef FL_QK_ARGS
   FL_CHECK_LAUNCH("fl_mla_quant_q_store_k");
   return FL_OK;
 }

@@ -70,8 +70,8 @@ def test_quant_roundtrip_random_bit_exact_vs_oracle(fm):
 
 def test_fused_quant_q_and_cache_k_matches_the_two_separate_calls(fm):
     """K5 + K4 in one launch (flash_mla_fp8.quantize_q_and_cache_k): bytes identical to quantize_and_cache_k followed by
-    quantize_ckv_per_token_head, at decode sizes (one row per wave) and above 8192 rows (two rows per wave, an odd number of
-    K rows so that a wave straddles the K / Q boundary); out-of-pool and negative cache locations are skipped as in K5."""
+    quantize_ckv_per_token_head, at decode sizes (one row per wave) and above 8192 rows (16 lanes per row, 4 rows per wave; an odd
+    number of K rows so that a wave straddles the K / Q boundary); out-of-pool and negative cache locations are skipped as in K5."""
     g = torch.Generator().manual_seed(33)
     for bs, H, s_q in ((3, 16, 1), (128, 128, 1), (65, 128, 4)):
         slots = 4096
