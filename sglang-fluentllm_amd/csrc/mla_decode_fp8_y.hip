@@ -992,7 +992,7 @@ int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipSt
   p.partial_bf16 = 1;   // split partials travel as bf16 rows
   static const int merge_env = [] {   // FLUENT_MLA_MERGE_KERNEL=1: always the merge kernel; =0: always in-kernel (tests); unset: the rule below
     const char* e = getenv("FLUENT_MLA_MERGE_KERNEL");
-    return e == nullptr ? -1 : (e[0] == '1' ? 1 : 0);
+    return (e == nullptr || e[0] == '\0') ? -1 : (e[0] == '1' ? 1 : 0);
   }();
   // in-kernel merge when splits are rare (at least as many requests as parts: a part boundary splits at most one
   // request, typically into 2-3 pieces); with fewer requests than parts EVERY request is cut into many pieces and the

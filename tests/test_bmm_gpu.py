@@ -16,7 +16,7 @@ def _ulp_close(got, ref32):
     return bool(((got.float() - ref_b).abs() <= tol).all())
 
 
-@pytest.mark.parametrize("T,H", [(1, 16), (37, 16), (128, 128), (256, 32)])
+@pytest.mark.parametrize("T,H", [(1, 16), (37, 16), (128, 128), (256, 32), (300, 128), (700, 128)])
 def test_weight_absorption_bmm_pair_matches_fp32_reference(T, H):
     from fluent_mi355.bmm import bmm
     g = torch.Generator().manual_seed(T + H)
