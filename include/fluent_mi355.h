@@ -328,6 +328,15 @@ int fl_bmm_bf16_nt(const void* A, const void* B, void* C, int batch, int64_t M, 
                    int64_t a_stride_m, int64_t b_stride_b, int64_t b_stride_n, int64_t c_stride_b, int64_t c_stride_m,
                    int out_is_f32, fl_stream_t stream);
 
+/* The same product (one batch) split over K across workgroups, for few output tiles and a long K — the router GEMM
+ * flashinfer.dsv3_router_gemm (srt/models/deepseek_v2.py:177-179: hidden [T, 7168] x gate weight [256, 7168]^T -> f32 logits):
+ * f32 partials in `workspace` (at least fl_gemm_bf16_nt_splitk_workspace_bytes(M, N, K) bytes, 16-byte aligned; launches that
+ * share it must be ordered), summed in split order by a second launch (deterministic).  N % 64 == 0, K % 64 == 0. */
+int64_t fl_gemm_bf16_nt_splitk_workspace_bytes(int64_t M, int N, int K);
+int fl_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, int64_t M, int N, int K, int64_t a_stride_m,
+                           int64_t b_stride_n, int64_t c_stride_m, int out_is_f32, void* workspace, int64_t workspace_bytes,
+                           fl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

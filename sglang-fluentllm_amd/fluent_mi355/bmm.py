@@ -40,10 +40,40 @@ def bmm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, out_d
     return out
 
 
+lib.fl_gemm_bf16_nt_splitk_workspace_bytes.argtypes = [_i64, _i32, _i32]
+lib.fl_gemm_bf16_nt_splitk_workspace_bytes.restype = _i64
+lib.fl_gemm_bf16_nt_splitk.argtypes = [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _i64, _vp]
+lib.fl_gemm_bf16_nt_splitk.restype = _i32
+_SPLITK_WS_MAX = 64 << 20
+_splitk_ws = {}
+
+
+def _router_workspace(device, nbytes):
+    """f32 partials of the split-K router GEMM: one buffer per (device, stream), grown on demand"""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr(device))
+    ws = _splitk_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _splitk_ws[key] = torch.empty(max(nbytes, 8 << 20), dtype=torch.uint8, device=device)
+    return ws
+
+
 def dsv3_router_gemm(hidden_states: torch.Tensor, weight: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """router logits hidden [T, K] x weight [E, K]^T (models/deepseek_v2.py:177-179) -> [T, E] in `out_dtype`"""
     if hidden_states.dim() != 2 or weight.dim() != 2 or hidden_states.shape[1] != weight.shape[1]:
         raise RuntimeError("dsv3_router_gemm: hidden [T, K], weight [E, K]")
+    T, K = hidden_states.shape
+    E = weight.shape[0]
+    if (hidden_states.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and hidden_states.is_cuda and T > 0 and E % 64 == 0
+            and K % 64 == 0 and hidden_states.stride(1) == 1 and weight.stride(1) == 1 and out_dtype in (torch.float32, torch.bfloat16)):
+        need = int(lib.fl_gemm_bf16_nt_splitk_workspace_bytes(T, E, K))
+        if 0 < need <= _SPLITK_WS_MAX and hidden_states.stride(0) % 8 == 0 and weight.stride(0) % 8 == 0:
+            # few output tiles, long K: k split across workgroups + a deterministic reduce (csrc/bmm_bf16.hip, B3)
+            ws = _router_workspace(hidden_states.device, need)
+            out = torch.empty(T, E, dtype=out_dtype, device=hidden_states.device)
+            check(lib.fl_gemm_bf16_nt_splitk(hidden_states.data_ptr(), weight.data_ptr(), out.data_ptr(), T, E, K, hidden_states.stride(0),
+                                             weight.stride(0), out.stride(0), int(out_dtype == torch.float32), ws.data_ptr(), ws.numel(),
+                                             stream_ptr(hidden_states.device)), "fl_gemm_bf16_nt_splitk")
+            return out
     o = bmm(hidden_states.unsqueeze(0), weight.unsqueeze(0).transpose(1, 2),
             out_dtype=torch.float32 if out_dtype == torch.float32 else torch.bfloat16)[0]
     return o if o.dtype == out_dtype else o.to(out_dtype)

@@ -25,7 +25,12 @@ def timeit(fn):
     for _ in range(20): gr.replay()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / 160
+import flashinfer
+wr = (torch.randn(256, 7168, device=dev, generator=g) * 0.02).to(torch.bfloat16)
 for T in (int(a) for a in (sys.argv[1:] or ["16", "128", "256"])):
+    xr = torch.randn(T, 7168, device=dev, generator=g).to(torch.bfloat16)
+    tr = timeit(lambda: flashinfer.dsv3_router_gemm(xr, wr, out_dtype=torch.float32))
+    tl = timeit(lambda: torch.nn.functional.linear(xr, wr))
     q = torch.randn(T, H, 192, device=dev, generator=g).to(torch.bfloat16)
     Q = torch.empty(T, H, 576, dtype=torch.bfloat16, device=dev)
     att = torch.randn(T, H, 512, device=dev, generator=g).to(torch.bfloat16)
@@ -33,4 +38,5 @@ for T in (int(a) for a in (sys.argv[1:] or ["16", "128", "256"])):
     tv = timeit(lambda: bmm(att.transpose(0, 1), wvc))
     tt = timeit(lambda: torch.bmm(att.transpose(0, 1), wvc))
     print(json.dumps({"wlds": os.environ.get("FLUENT_BMM_WLDS", "default"), "T": T, "H": H, "q_absorb_us": round(tq, 1), "v_absorb_us": round(tv, 1),
-                      "torch_bmm_v_absorb_us": round(tt, 1)}))
+                      "torch_bmm_v_absorb_us": round(tt, 1),
+                      "router_gemm_f32_us": round(tr, 1), "torch_linear_bf16_router_us": round(tl, 1)}))
