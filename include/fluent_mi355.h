@@ -66,6 +66,39 @@ int fl_mla_quant_q_store_k(const void* key, int64_t n_k, const int32_t* indices,
                            void* k_rope_cache, int64_t num_slots, const void* q, int64_t q_rows, int d_nope, int d_rope,
                            void* q_nope, float* q_scale, void* q_rope, fl_stream_t stream);
 
+/* ---- A2: the query side of the decode layer before the attention kernel, in ONE launch (an extension, like the entry point
+ * above: INTEGRATION.md section 4) — torch.bmm(q_nope.transpose(0,1), w_kc) (srt/models/deepseek_v2.py:840), the rotary embedding of
+ * q_pe and k_pe (:842-858), set_kv_buffer / K5 (flashmla_backend.py:188-196) and quantize_ckv_per_token_head / K4 (:198-206).
+ * Outputs are K4's and K5's, bit-identical to the four-launch chain; the bf16 absorbed query is never written.
+ * q [T, H, 192] bf16 (nope 128 | rope 64; element strides), w_kc [H, 512, 128] bf16 k-contiguous (head stride in elements),
+ * cos_sin_cache [max_position, 64] f32 (cos 32 | sin 32), latent [T, 576] bf16 (k_nope | k_pe: k_pe is rotated IN PLACE; NULL = no
+ * K rows), cache_loc i32 [T] (rows outside [0, num_slots) are skipped), outputs contiguous [T, H, 512] e4m3 / [T, H] f32 /
+ * [T, H, 64] bf16. ---- */
+typedef struct FlMlaAbsorbArgs {
+  const void* q;
+  int64_t q_stride_token, q_stride_head;
+  int64_t num_tokens;
+  int32_t num_heads;
+  int32_t d_nope, d_rope, d_lora;   /* 128, 64, 512 */
+  const void* w_kc;
+  int64_t w_stride_head;
+  const int64_t* positions;
+  const float* cos_sin_cache;
+  int64_t max_position;
+  int32_t is_neox;
+  void* latent;
+  int64_t latent_stride;
+  const int32_t* cache_loc;
+  void* k_lora_cache;
+  float* k_scale_cache;
+  void* k_rope_cache;
+  int64_t num_slots;
+  void* q_nope_out;
+  float* q_scale_out;
+  void* q_rope_out;
+} FlMlaAbsorbArgs;
+int fl_mla_absorb_rope_quant(const FlMlaAbsorbArgs* args, fl_stream_t stream);
+
 /* ---- K6: dequantize_ckv_fused_indexed (memory_pool.py:821-824; fallback :826-831) ---- */
 int fl_mla_dequant_gather(const void* k_lora_cache, const void* k_rope_cache, const float* k_scale_cache,
                           const int32_t* indices, int64_t n, int d_nope, int d_rope, int64_t num_slots,

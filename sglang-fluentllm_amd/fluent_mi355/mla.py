@@ -113,6 +113,66 @@ def quantize_q_and_cache_k(q: torch.Tensor, key: torch.Tensor, k_lora_cache: tor
     return q_nope, q_scale, q_rope
 
 
+class _FlMlaAbsorbArgs(ctypes.Structure):
+    _fields_ = [("q", ctypes.c_void_p), ("q_stride_token", ctypes.c_int64), ("q_stride_head", ctypes.c_int64),
+                ("num_tokens", ctypes.c_int64), ("num_heads", ctypes.c_int32), ("d_nope", ctypes.c_int32), ("d_rope", ctypes.c_int32),
+                ("d_lora", ctypes.c_int32), ("w_kc", ctypes.c_void_p), ("w_stride_head", ctypes.c_int64),
+                ("positions", ctypes.c_void_p), ("cos_sin_cache", ctypes.c_void_p), ("max_position", ctypes.c_int64),
+                ("is_neox", ctypes.c_int32), ("latent", ctypes.c_void_p), ("latent_stride", ctypes.c_int64),
+                ("cache_loc", ctypes.c_void_p), ("k_lora_cache", ctypes.c_void_p), ("k_scale_cache", ctypes.c_void_p),
+                ("k_rope_cache", ctypes.c_void_p), ("num_slots", ctypes.c_int64), ("q_nope_out", ctypes.c_void_p),
+                ("q_scale_out", ctypes.c_void_p), ("q_rope_out", ctypes.c_void_p)]
+
+
+lib.fl_mla_absorb_rope_quant.argtypes = [ctypes.POINTER(_FlMlaAbsorbArgs), ctypes.c_void_p]
+lib.fl_mla_absorb_rope_quant.restype = ctypes.c_int
+
+
+def absorb_rope_quant(q: torch.Tensor, w_kc: torch.Tensor, positions: torch.Tensor, cos_sin_cache: torch.Tensor,
+                      latent_cache: torch.Tensor = None, k_lora_cache: torch.Tensor = None, k_lora_scale_cache: torch.Tensor = None,
+                      k_rope_cache: torch.Tensor = None, indices: torch.Tensor = None, is_neox: bool = False):
+    """The query side of DeepseekV2AttentionMLA.forward_absorb_prepare + FlashMLABackend.forward_decode's two quantisers in ONE launch
+    (srt/models/deepseek_v2.py:830-861, flashmla_backend.py:188-206): `torch.bmm(q_nope.transpose(0,1), w_kc)`, the rotary embedding of
+    q_pe and k_pe, `quantize_and_cache_k` and `quantize_ckv_per_token_head` — the bf16 absorbed query is never written.
+      q [T, H, 192] bf16 (nope 128 | rope 64; any token / head strides), w_kc [H, 128, 512] as the model holds it (the transposed view
+      of a k-contiguous [H, 512, 128], deepseek_v2.py:1632), positions [T], cos_sin_cache [max_position, 64] f32,
+      latent_cache [T, 576] bf16 (k_nope | k_pe — k_pe is rotated IN PLACE like the reference's call) with the three cache tensors and
+      `indices` (cache locations): optional as a group.
+    Returns (q_nope fp8 [T, H, 512], q_scale f32 [T, H, 1], q_rope bf16 [T, H, 64]) — the inputs of flash_mla_ckv_fp8_per_token —
+    bit-identical to the four-launch chain.  An extension over the reference's module."""
+    _req(q.is_cuda and q.dtype == torch.bfloat16 and q.dim() == 3 and q.shape[2] == 192 and q.stride(2) == 1, "q must be bf16 [T, H, 192]")
+    T, H = q.shape[0], q.shape[1]
+    _req(w_kc.is_cuda and w_kc.dtype == torch.bfloat16 and tuple(w_kc.shape) == (H, 128, 512) and w_kc.stride(1) == 1 and w_kc.stride(2) == 128,
+         "w_kc must be the [H, 128, 512] view of a k-contiguous [H, 512, 128] bf16 tensor")
+    _req(cos_sin_cache.is_cuda and cos_sin_cache.dtype == torch.float32 and cos_sin_cache.dim() == 2 and cos_sin_cache.shape[1] == 64
+         and cos_sin_cache.is_contiguous(), "cos_sin_cache must be contiguous f32 [max_position, 64]")
+    pos = positions.reshape(-1).to(torch.int64).contiguous()
+    _req(pos.numel() == T and pos.is_cuda, "positions must hold one entry per token")
+    a = _FlMlaAbsorbArgs()
+    a.q, a.q_stride_token, a.q_stride_head, a.num_tokens, a.num_heads = q.data_ptr(), q.stride(0), q.stride(1), T, H
+    a.d_nope, a.d_rope, a.d_lora = 128, 64, 512
+    a.w_kc, a.w_stride_head = w_kc.data_ptr(), w_kc.stride(0)
+    a.positions, a.cos_sin_cache, a.max_position, a.is_neox = pos.data_ptr(), cos_sin_cache.data_ptr(), cos_sin_cache.shape[0], int(bool(is_neox))
+    if latent_cache is not None:
+        for t, n in ((k_lora_cache, "k_lora_cache"), (k_lora_scale_cache, "k_lora_scale_cache"), (k_rope_cache, "k_rope_cache"), (indices, "indices")):
+            _req(t is not None, f"{n} is required with latent_cache")
+            _cuda_contig(t, n)
+        lat = latent_cache.view(-1, latent_cache.shape[-1])
+        _req(lat.is_cuda and lat.dtype == torch.bfloat16 and lat.shape == (T, 576) and lat.stride(1) == 1, "latent_cache must be bf16 [T, 576]")
+        _req(k_lora_cache.dtype in _ONE_BYTE and k_lora_scale_cache.dtype == torch.float32 and k_rope_cache.dtype == torch.bfloat16,
+             "bad cache dtypes")
+        _req(indices.dtype == torch.int32 and indices.numel() == T, "indices must be int32 [T]")
+        a.latent, a.latent_stride, a.cache_loc = lat.data_ptr(), lat.stride(0), indices.data_ptr()
+        a.k_lora_cache, a.k_scale_cache, a.k_rope_cache = k_lora_cache.data_ptr(), k_lora_scale_cache.data_ptr(), k_rope_cache.data_ptr()
+        a.num_slots = k_lora_cache.numel() // 512
+    q_nope = torch.empty(T, H, 512, dtype=torch.float8_e4m3fn, device=q.device)
+    q_scale = torch.empty(T, H, 1, dtype=torch.float32, device=q.device)
+    q_rope = torch.empty(T, H, 64, dtype=torch.bfloat16, device=q.device)
+    a.q_nope_out, a.q_scale_out, a.q_rope_out = q_nope.data_ptr(), q_scale.data_ptr(), q_rope.data_ptr()
+    check(lib.fl_mla_absorb_rope_quant(ctypes.byref(a), stream_ptr(q.device)), "fl_mla_absorb_rope_quant")
+    return q_nope, q_scale, q_rope
+
+
 def dequantize_ckv_fused_indexed(k_lora_fp8: torch.Tensor, k_rope: torch.Tensor, k_scale: torch.Tensor,
                                  indices: torch.Tensor):
     """-> (k_lora_deq bf16 [n,1,512], k_rope_deq bf16 [n,1,64]) gathered at `indices`."""
