@@ -257,27 +257,31 @@ int fl_ep_route(const int32_t* indices /*[num_pairs] global expert ids*/, int64_
 /* Token-once-per-peer routing of the same dispatch (fluent_mi355/ep.py): tok_slot [tokens, world] = the token's row in
  * each peer slab (-1: none of its experts lives there), send_eid [world*cap, top_k] = local expert ids per slab row (-1
  * padded), pair_src [world*cap, top_k] = t*top_k + k of the (token, expert) pair behind every slab pair (-1 padded): the
- * layout the combine weights travel in (fl_ep_gather_f32). */
+ * layout the combine weights travel in (fl_ep_gather_f32).
+ * ROW STRIDES (round 3): the ids (and, when the caller has them at dispatch time, the routing weights) can travel in the TAIL of
+ * their slab row — message row = [hidden bf16 | top_k int32 ids | top_k f32 weights] — so that a direction is ONE all-to-all
+ * instead of two.  The `*_row_stride` arguments are the distance between consecutive rows of that tensor in ITS OWN element
+ * type (int32 / f32 / bf16); 0 = dense ([rows, top_k] resp. [rows, hidden]). */
 int fl_ep_route_dedup(const int32_t* indices /*[tokens, top_k] global expert ids*/, int64_t num_tokens, int top_k,
                       int experts_per_rank, int world, int cap, int32_t* tok_slot, int32_t* send_eid, int32_t* pair_src,
-                      fl_stream_t stream);
+                      int64_t eid_row_stride, fl_stream_t stream);
 int fl_ep_gather_f32(const float* vals, int64_t n, const int32_t* src /*[out_n]*/, float* out /*out[j] = vals[src[j]], 0 where src[j] is not in [0, n)*/,
-                     int64_t out_n, fl_stream_t stream);
+                     int64_t out_n, int per_row /*entries per output row*/, int64_t out_row_stride, fl_stream_t stream);
 int fl_ep_gather_rows_div(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int div /*dst[i] = src[idx[i] / div]*/,
                           int hidden, void* dst, int64_t dst_rows,
                           const int32_t* n_valid /*optional DEVICE scalar: only rows i < *n_valid are copied (the launch is sized for n)*/,
-                          fl_stream_t stream);
-int fl_ep_sort(const int32_t* recv_eid /*[num_slots]*/, int64_t num_slots, int num_local_experts,
+                          int64_t src_row_stride, fl_stream_t stream);
+int fl_ep_sort(const int32_t* recv_eid /*[num_slots] = [rows, per_row]*/, int64_t num_slots, int num_local_experts,
                int32_t* order /*[num_slots] slots grouped by expert, invalid last*/, int32_t* exclusive_sum /*[E_l+1]*/,
-               int32_t* inverse /*optional [num_slots]: inverse[order[i]] = i*/, fl_stream_t stream);
+               int32_t* inverse /*optional [num_slots]: inverse[order[i]] = i*/, int per_row, int64_t eid_row_stride, fl_stream_t stream);
 int fl_ep_gather_rows(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int hidden, void* dst,
                       int64_t dst_rows, fl_stream_t stream);   /* dst[i] = src[idx[i]] */
 int fl_ep_scatter_rows(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int hidden, void* dst,
                        int64_t dst_rows, fl_stream_t stream);  /* dst[idx[i]] = src[i] */
 int fl_ep_send_rows(const void* x, int64_t num_tokens, const int32_t* send_slot /*[num_pairs]*/, int64_t num_pairs, int top_k,
-                    int hidden, void* send_buf, int64_t send_rows, fl_stream_t stream);  /* send_buf[send_slot[p]] = x[p / top_k] */
+                    int hidden, void* send_buf, int64_t send_rows, int64_t send_row_stride, fl_stream_t stream);  /* send_buf[send_slot[p]] = x[p / top_k] */
 int fl_ep_combine(const void* ret_rows, int64_t num_ret_rows, const int32_t* send_slot, const float* weights,
-                  int64_t num_tokens, int top_k, int hidden, void* out, fl_stream_t stream);
+                  int64_t num_tokens, int top_k, int hidden, void* out, int64_t weight_row_stride, fl_stream_t stream);
 
 /* A1-masked: silu_and_mul_masked_post_quant_fwd (srt/layers/moe/executors/deep_ep_executor.py:106-170, Triton kernel :31-104)
  * between the two masked grouped GEMMs of the low-latency DeepEP path: x bf16 [G, rows_per_group, 2I] contiguous; only rows

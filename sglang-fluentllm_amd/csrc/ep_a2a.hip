@@ -47,11 +47,13 @@ __global__ __launch_bounds__(256) void ep_route_kernel(const int32_t* __restrict
 __global__ __launch_bounds__(256) void ep_route_dedup_kernel(const int32_t* __restrict__ indices, int T, int top_k,
                                                              int experts_per_rank, int world, int cap,
                                                              int32_t* __restrict__ tok_slot, int32_t* __restrict__ send_eid,
-                                                             int32_t* __restrict__ pair_src) {
+                                                             int32_t* __restrict__ pair_src, long long eid_stride) {
+  // (eid_stride: ints between the id rows — top_k for a separate [rows, top_k] tensor, the message row for ids that travel in the
+  //  TAIL of their slab row: one all-to-all instead of two)
   extern __shared__ unsigned long long s_mask[];   // [T] peers of every token (world <= 64)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long long i = threadIdx.x; i < (long long)world * cap * top_k; i += 256) {
-    send_eid[i] = -1;
+    send_eid[(i / top_k) * eid_stride + i % top_k] = -1;
     pair_src[i] = -1;
   }
   for (int t = threadIdx.x; t < T; t += 256) {
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void ep_route_dedup_kernel(const int32_t* __re
             const int e2 = indices[t * top_k + k2];
             j += (e2 >= 0 && e2 < experts_per_rank * world && e2 / experts_per_rank == d) ? 1 : 0;
           }
-          send_eid[(long long)row * top_k + j] = e - d * experts_per_rank;
+          send_eid[(long long)row * eid_stride + j] = e - d * experts_per_rank;
           pair_src[(long long)row * top_k + j] = t * top_k + k;
         }
       }
@@ -98,23 +100,25 @@ __global__ __launch_bounds__(256) void ep_route_dedup_kernel(const int32_t* __re
 
 // out[j] = vals[src[j]] where src[j] names a value (0 <= src[j] < n), else 0: the combine weights in the slab-pair layout
 __global__ __launch_bounds__(256) void ep_gather_f32_kernel(const float* __restrict__ vals, long long n, const int32_t* __restrict__ src,
-                                                            long long out_n, float* __restrict__ out) {
+                                                            long long out_n, float* __restrict__ out, int per_row, long long out_stride) {
   const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
   if (j < out_n) {
     const long long i = src[j];
-    out[j] = (i >= 0 && i < n) ? vals[i] : 0.f;
+    out[(j / per_row) * out_stride + j % per_row] = (i >= 0 && i < n) ? vals[i] : 0.f;
   }
 }
 
-__global__ __launch_bounds__(256) void ep_sort_kernel(const int32_t* __restrict__ recv_eid, int S, int E,
+__global__ __launch_bounds__(256) void ep_sort_kernel(const int32_t* __restrict__ recv_eid_base, int S, int E,
                                                       int32_t* __restrict__ order, int32_t* __restrict__ exclusive_sum,
-                                                      int32_t* __restrict__ inv /*optional: inv[order[i]] = i*/) {
+                                                      int32_t* __restrict__ inv /*optional: inv[order[i]] = i*/, int per_row,
+                                                      long long eid_stride) {
+  auto eid_at = [&](int i) { return recv_eid_base[(long long)(i / per_row) * eid_stride + i % per_row]; };
   extern __shared__ int bins[];   // E + 1 counters, then E + 1 cursors
   int* cur = bins + E + 1;
   for (int i = threadIdx.x; i <= E; i += 256) bins[i] = 0;
   __syncthreads();
   for (int i = threadIdx.x; i < S; i += 256) {
-    const int e = recv_eid[i];
+    const int e = eid_at(i);
     atomicAdd(&bins[(e >= 0 && e < E) ? e : E], 1);
   }
   __syncthreads();
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void ep_sort_kernel(const int32_t* __restrict_
   }
   __syncthreads();
   for (int i = threadIdx.x; i < S; i += 256) {
-    const int e = recv_eid[i];
+    const int e = eid_at(i);
     const int pos = atomicAdd(&cur[(e >= 0 && e < E) ? e : E], 1);
     order[pos] = i;   // invalid slots end up after every valid row
     if (inv != nullptr) inv[i] = pos;
@@ -144,7 +148,10 @@ template <bool kScatter>
 __global__ __launch_bounds__(256) void ep_rows_kernel(const uint16_t* __restrict__ src, const int32_t* __restrict__ idx,
                                                       long long n, int hidden, long long src_rows, long long dst_rows,
                                                       uint16_t* __restrict__ dst, int src_div,
-                                                      const int32_t* __restrict__ n_valid = nullptr) {
+                                                      const int32_t* __restrict__ n_valid = nullptr, long long src_stride = 0,
+                                                      long long dst_stride = 0) {
+  src_stride = src_stride > 0 ? src_stride : hidden;   // (elements between rows: a slab row may carry a tail behind its `hidden` elements)
+  dst_stride = dst_stride > 0 ? dst_stride : hidden;
   const long long i = blockIdx.x;
   if (n_valid != nullptr && i >= *n_valid) return;   // (device-side row count: the static grid covers the worst case)
   const long long j = idx[i];
@@ -152,8 +159,8 @@ __global__ __launch_bounds__(256) void ep_rows_kernel(const uint16_t* __restrict
   const long long s = kScatter ? (long long)((unsigned)i / (unsigned)src_div) : (j < 0 ? j : j / src_div), d = kScatter ? j : i;
   if (s < 0 || s >= src_rows || d < 0 || d >= dst_rows) return;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4* sp = reinterpret_cast<const u32x4*>(src + s * hidden);
-  u32x4* dp = reinterpret_cast<u32x4*>(dst + d * hidden);
+  const u32x4* sp = reinterpret_cast<const u32x4*>(src + s * src_stride);
+  u32x4* dp = reinterpret_cast<u32x4*>(dst + d * dst_stride);
   const int nc = hidden / 8;
   for (int c0 = threadIdx.x; c0 < nc; c0 += 4 * 256) {
     // loads are unconditional on a clamped column (a predicated load into an array makes hipcc stage it through LDS
@@ -174,7 +181,8 @@ __global__ __launch_bounds__(256) void ep_rows_kernel(const uint16_t* __restrict
 // expert order k = 0 .. top_k-1 in fp32 as before.
 __global__ __launch_bounds__(256) void ep_combine_kernel(const uint16_t* __restrict__ ret, const int32_t* __restrict__ slot,
                                                          const float* __restrict__ w, long long t_count, int top_k,
-                                                         int hidden, long long ret_rows, uint16_t* __restrict__ out) {
+                                                         int hidden, long long ret_rows, uint16_t* __restrict__ out,
+                                                         long long w_stride) {
   __shared__ long long s_slot[64];
   __shared__ float s_w[64];
   const int tid = threadIdx.x;
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) void ep_combine_kernel(const uint16_t* __restr
     __syncthreads();
     if (tid < 64 && k0 + tid < top_k) {
       const long long sl = slot[t * top_k + k0 + tid];
-      const float wv = w[t * top_k + k0 + tid];
+      const float wv = w[t * w_stride + k0 + tid];
       // a zero weight skips the row altogether (0 x an uncomputed row must not turn into NaN: the padding pairs of a slab
       // row sort behind the last expert group, where the expert output buffer was never written)
       const bool ok = sl >= 0 && sl < ret_rows && wv != 0.f;
@@ -243,40 +251,47 @@ extern "C" int fl_ep_route(const int32_t* indices, int64_t num_pairs, int expert
 }
 
 extern "C" int fl_ep_route_dedup(const int32_t* indices, int64_t num_tokens, int top_k, int experts_per_rank, int world, int cap,
-                                 int32_t* tok_slot, int32_t* send_eid, int32_t* pair_src, fl_stream_t stream) {
+                                 int32_t* tok_slot, int32_t* send_eid, int32_t* pair_src, int64_t eid_row_stride, fl_stream_t stream) {
+  FL_CHECK_ARG(eid_row_stride == 0 || eid_row_stride >= top_k, "fl_ep_route_dedup: eid_row_stride=%lld < top_k", (long long)eid_row_stride);
   FL_CHECK_ARG(send_eid && pair_src && (num_tokens == 0 || (indices && tok_slot)), "fl_ep_route_dedup: null pointer");
   FL_CHECK_ARG(world >= 1 && world <= 64 && cap >= 1 && experts_per_rank >= 1 && top_k >= 1 && num_tokens >= 0 &&
                    num_tokens <= 8192, "fl_ep_route_dedup: bad sizes (tokens per rank <= 8192, world <= 64)");
   ep_route_dedup_kernel<<<1, 256, (size_t)(num_tokens > 0 ? num_tokens : 1) * 8, (hipStream_t)stream>>>(
-      indices, (int)num_tokens, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_src);
+      indices, (int)num_tokens, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_src,
+      eid_row_stride > 0 ? eid_row_stride : top_k);
   FL_CHECK_LAUNCH("fl_ep_route_dedup");
   return FL_OK;
 }
 
-extern "C" int fl_ep_gather_f32(const float* vals, int64_t n, const int32_t* src, float* out, int64_t out_n, fl_stream_t stream) {
+extern "C" int fl_ep_gather_f32(const float* vals, int64_t n, const int32_t* src, float* out, int64_t out_n, int per_row,
+                                int64_t out_row_stride, fl_stream_t stream) {
   FL_CHECK_ARG(out_n >= 0 && n >= 0 && (out_n == 0 || (out && src)) && (n == 0 || vals), "fl_ep_gather_f32: bad args");
+  FL_CHECK_ARG(per_row >= 1 && (out_row_stride == 0 || out_row_stride >= per_row), "fl_ep_gather_f32: bad row layout");
   if (out_n == 0) return FL_OK;
-  ep_gather_f32_kernel<<<dim3((unsigned)((out_n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(vals, n, src, out_n, out);
+  ep_gather_f32_kernel<<<dim3((unsigned)((out_n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
+      vals, n, src, out_n, out, per_row, out_row_stride > 0 ? out_row_stride : per_row);
   FL_CHECK_LAUNCH("fl_ep_gather_f32");
   return FL_OK;
 }
 
 extern "C" int fl_ep_gather_rows_div(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int div, int hidden,
-                                     void* dst, int64_t dst_rows, const int32_t* n_valid, fl_stream_t stream) {
+                                     void* dst, int64_t dst_rows, const int32_t* n_valid, int64_t src_row_stride, fl_stream_t stream) {
   if (n == 0) return FL_OK;
   FL_CHECK_ARG(src && idx && dst && hidden % 8 == 0 && div >= 1, "fl_ep_gather_rows_div: bad args");
+  FL_CHECK_ARG(src_row_stride == 0 || (src_row_stride >= hidden && src_row_stride % 8 == 0), "fl_ep_gather_rows_div: bad source row stride");
   ep_rows_kernel<false><<<dim3((unsigned)n), 256, 0, (hipStream_t)stream>>>(
-      (const uint16_t*)src, idx, n, hidden, src_rows, dst_rows, (uint16_t*)dst, div, n_valid);
+      (const uint16_t*)src, idx, n, hidden, src_rows, dst_rows, (uint16_t*)dst, div, n_valid, src_row_stride, 0);
   FL_CHECK_LAUNCH("fl_ep_gather_rows_div");
   return FL_OK;
 }
 
 extern "C" int fl_ep_sort(const int32_t* recv_eid, int64_t num_slots, int num_local_experts, int32_t* order,
-                          int32_t* exclusive_sum, int32_t* inverse, fl_stream_t stream) {
+                          int32_t* exclusive_sum, int32_t* inverse, int per_row, int64_t eid_row_stride, fl_stream_t stream) {
   FL_CHECK_ARG(recv_eid && order && exclusive_sum, "fl_ep_sort: null pointer");
   FL_CHECK_ARG(num_local_experts >= 1 && num_local_experts <= 4096 && num_slots >= 0, "fl_ep_sort: bad sizes");
+  FL_CHECK_ARG(per_row >= 1 && (eid_row_stride == 0 || eid_row_stride >= per_row), "fl_ep_sort: bad row layout");
   ep_sort_kernel<<<1, 256, 2 * (num_local_experts + 1) * sizeof(int), (hipStream_t)stream>>>(
-      recv_eid, (int)num_slots, num_local_experts, order, exclusive_sum, inverse);
+      recv_eid, (int)num_slots, num_local_experts, order, exclusive_sum, inverse, per_row, eid_row_stride > 0 ? eid_row_stride : per_row);
   FL_CHECK_LAUNCH("fl_ep_sort");
   return FL_OK;
 }
@@ -302,21 +317,24 @@ extern "C" int fl_ep_scatter_rows(const void* src, int64_t src_rows, const int32
 }
 
 extern "C" int fl_ep_send_rows(const void* x, int64_t num_tokens, const int32_t* send_slot, int64_t num_pairs, int top_k,
-                               int hidden, void* send_buf, int64_t send_rows, fl_stream_t stream) {
+                               int hidden, void* send_buf, int64_t send_rows, int64_t send_row_stride, fl_stream_t stream) {
   if (num_pairs == 0) return FL_OK;
   FL_CHECK_ARG(x && send_slot && send_buf && hidden % 8 == 0 && top_k >= 1, "fl_ep_send_rows: bad args");
+  FL_CHECK_ARG(send_row_stride == 0 || (send_row_stride >= hidden && send_row_stride % 8 == 0), "fl_ep_send_rows: bad row stride");
   ep_rows_kernel<true><<<dim3((unsigned)num_pairs), 256, 0, (hipStream_t)stream>>>(
-      (const uint16_t*)x, send_slot, num_pairs, hidden, num_tokens, send_rows, (uint16_t*)send_buf, top_k);
+      (const uint16_t*)x, send_slot, num_pairs, hidden, num_tokens, send_rows, (uint16_t*)send_buf, top_k, nullptr, 0, send_row_stride);
   FL_CHECK_LAUNCH("fl_ep_send_rows");
   return FL_OK;
 }
 
 extern "C" int fl_ep_combine(const void* ret_rows, int64_t num_ret_rows, const int32_t* send_slot, const float* weights,
-                             int64_t num_tokens, int top_k, int hidden, void* out, fl_stream_t stream) {
+                             int64_t num_tokens, int top_k, int hidden, void* out, int64_t weight_row_stride, fl_stream_t stream) {
   if (num_tokens == 0) return FL_OK;
   FL_CHECK_ARG(ret_rows && send_slot && weights && out && hidden % 8 == 0 && top_k >= 1, "fl_ep_combine: bad args");
+  FL_CHECK_ARG(weight_row_stride == 0 || weight_row_stride >= top_k, "fl_ep_combine: bad weight row stride");
   ep_combine_kernel<<<dim3((unsigned)num_tokens, (unsigned)((hidden / 8 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
-      (const uint16_t*)ret_rows, send_slot, weights, num_tokens, top_k, hidden, num_ret_rows, (uint16_t*)out);
+      (const uint16_t*)ret_rows, send_slot, weights, num_tokens, top_k, hidden, num_ret_rows, (uint16_t*)out,
+      weight_row_stride > 0 ? weight_row_stride : top_k);
   FL_CHECK_LAUNCH("fl_ep_combine");
   return FL_OK;
 }

@@ -9,9 +9,12 @@ Slab sizing: a token travels to a rank ONCE, however many of its top-k experts l
 the row to its experts locally; on the way back it returns ONE row per token, the weighted sum over its local experts).
 A peer slab therefore holds `max_tokens_per_rank` rows — the true worst case of that scheme, reached only if every token
 of a rank routes to the same peer — instead of `max_tokens_per_rank * top_k` rows for one row per (token, expert) pair:
-8x fewer xGMI bytes at top-8, and a slab cannot overflow (a token occupies at most one row of it).  Per direction:
-  dispatch: rows [world*cap, hidden] + local expert ids [world*cap, top_k] (two all_to_all_single, the second 32 B/row)
-  combine : weights [world*cap, top_k] f32 (tiny) + rows [world*cap, hidden]
+8x fewer xGMI bytes at top-8, and a slab cannot overflow (a token occupies at most one row of it).  Messages (round 3):
+  dispatch: ONE all_to_all_single of rows [world*cap, hidden | top_k int32 local expert ids | top_k f32 weights] — the ids (and the
+            routing weights, when `dispatch(..., weights=)` is given them) travel in the TAIL of their slab row (+64 B on 14 KiB)
+  combine : rows [world*cap, hidden] back — ONE all_to_all_single when the weights went out with the dispatch; otherwise (the
+            reference's call order: `AllToAll.dispatch` is not given the weights, fast_ep.py:45-51) the weights follow as a second,
+            32 B/row message at combine time, as before
 The integer / row work around the exchanges runs in HIP kernels (csrc/ep_a2a.hip).  `row_ops` exists so that the
 multi-process HOST logic can be exercised on CPU tensors with the gloo backend in tests (tests/ inject a torch-indexing
 implementation); the product default is the HIP one and there is no automatic fallback."""
@@ -32,14 +35,14 @@ class HipRowOps:
         self._ct, self._check, self._lib, self._stream = ctypes, check, lib, stream_ptr
         vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
         lib.fl_ep_route.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp]
-        lib.fl_ep_route_dedup.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp]
-        lib.fl_ep_sort.argtypes = [vp, i64, i32, vp, vp, vp, vp]
+        lib.fl_ep_route_dedup.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp, vp, i64, vp]
+        lib.fl_ep_sort.argtypes = [vp, i64, i32, vp, vp, vp, i32, i64, vp]
         lib.fl_ep_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
-        lib.fl_ep_gather_rows_div.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp, vp]
+        lib.fl_ep_gather_rows_div.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp, i64, vp]
         lib.fl_ep_scatter_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
-        lib.fl_ep_send_rows.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp]
-        lib.fl_ep_combine.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp]
-        lib.fl_ep_gather_f32.argtypes = [vp, i64, vp, vp, i64, vp]
+        lib.fl_ep_send_rows.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, i64, vp]
+        lib.fl_ep_combine.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, i64, vp]
+        lib.fl_ep_gather_f32.argtypes = [vp, i64, vp, vp, i64, i32, i64, vp]
         for n in ("fl_ep_route", "fl_ep_route_dedup", "fl_ep_sort", "fl_ep_gather_rows", "fl_ep_gather_rows_div",
                   "fl_ep_scatter_rows", "fl_ep_send_rows", "fl_ep_combine", "fl_ep_gather_f32"):
             getattr(lib, n).restype = i32
@@ -52,37 +55,50 @@ class HipRowOps:
             raise RuntimeError("expected a CUDA/HIP tensor")
         return stream_ptr(t.device)
 
+    # Row tensors may be VIEWS into a wider message row ([rows, cols] with stride(1) == 1 and any row stride): the kernels take
+    # the row stride in the view's own element type.
+    @staticmethod
+    def _rows2d(t, name):
+        if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+            raise RuntimeError(f"{name} must be a [rows, cols] tensor or view with a contiguous last dimension")
+        return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
     def route_dedup(self, indices, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_src):
+        """send_eid: int32 [world*cap, top_k] (a view into the message tail is fine)"""
         self._check(self._lib.fl_ep_route_dedup(indices.data_ptr(), indices.numel() // top_k, top_k, experts_per_rank, world, cap,
                                                 tok_slot.data_ptr(), send_eid.data_ptr(), pair_src.data_ptr(),
-                                                self._stream(send_eid.device)), "fl_ep_route_dedup")
+                                                self._rows2d(send_eid, "send_eid"), self._stream(send_eid.device)), "fl_ep_route_dedup")
 
     def sort(self, recv_eid, num_local_experts, order, exclusive_sum, inverse=None):
-        self._check(self._lib.fl_ep_sort(recv_eid.data_ptr(), recv_eid.numel(), num_local_experts, order.data_ptr(),
-                                         exclusive_sum.data_ptr(), None if inverse is None else inverse.data_ptr(),
-                                         self._stream(recv_eid.device)), "fl_ep_sort")
+        """recv_eid: int32 [rows, top_k] (view ok); order / inverse index the flattened (row, j) pairs"""
+        self._check(self._lib.fl_ep_sort(recv_eid.data_ptr(), recv_eid.shape[0] * recv_eid.shape[1], num_local_experts, order.data_ptr(),
+                                         exclusive_sum.data_ptr(), None if inverse is None else inverse.data_ptr(), recv_eid.shape[1],
+                                         self._rows2d(recv_eid, "recv_eid"), self._stream(recv_eid.device)), "fl_ep_sort")
 
     def gather_div(self, src, idx, n, div, dst, n_valid=None):
-        """dst[i] = src[idx[i] // div] for i < min(n, n_valid[0]) (n_valid: optional int32 device scalar)"""
+        """dst[i] = src[idx[i] // div] for i < min(n, n_valid[0]) (n_valid: optional int32 device scalar); src [rows, hidden] (view ok)"""
         self._check(self._lib.fl_ep_gather_rows_div(src.data_ptr(), src.shape[0], idx.data_ptr(), n, div, src.shape[1],
                                                     dst.data_ptr(), dst.shape[0], None if n_valid is None else n_valid.data_ptr(),
-                                                    self._stream(src.device)), "fl_ep_gather_rows_div")
+                                                    self._rows2d(src, "src"), self._stream(src.device)), "fl_ep_gather_rows_div")
 
     def send(self, x, send_slot, per_token, send_buf):
-        """send_buf[send_slot[p]] = x[p // per_token] for every entry p with a slot"""
+        """send_buf[send_slot[p]] = x[p // per_token] for every entry p with a slot; send_buf [rows, hidden] (view ok)"""
         self._check(self._lib.fl_ep_send_rows(x.data_ptr(), x.shape[0], send_slot.data_ptr(), send_slot.numel(), per_token, x.shape[1],
-                                              send_buf.data_ptr(), send_buf.shape[0], self._stream(send_buf.device)), "fl_ep_send_rows")
+                                              send_buf.data_ptr(), send_buf.shape[0], self._rows2d(send_buf, "send_buf"),
+                                              self._stream(send_buf.device)), "fl_ep_send_rows")
 
     def combine(self, rows, slot, weights, out, per_token):
-        """out[t] = sum_j weights[t, j] * rows[slot[t, j]] (slots < 0 or >= len(rows): skipped), fp32 accumulate"""
+        """out[t] = sum_j weights[t, j] * rows[slot[t, j]] (slots < 0 or >= len(rows): skipped), fp32 accumulate; weights: f32
+        [tokens, per_token] (view ok) or a flat tensor"""
+        w_stride = self._rows2d(weights, "weights") if weights.dim() == 2 else per_token
         self._check(self._lib.fl_ep_combine(rows.data_ptr(), rows.shape[0], slot.data_ptr(), weights.data_ptr(),
-                                            out.shape[0], per_token, out.shape[1], out.data_ptr(), self._stream(out.device)),
+                                            out.shape[0], per_token, out.shape[1], out.data_ptr(), w_stride, self._stream(out.device)),
                     "fl_ep_combine")
 
     def gather_f32(self, vals, src, out):
-        """out[j] = vals[src[j]] where src[j] names a value, else 0"""
-        self._check(self._lib.fl_ep_gather_f32(vals.data_ptr(), vals.numel(), src.data_ptr(), out.data_ptr(), out.numel(),
-                                               self._stream(out.device)), "fl_ep_gather_f32")
+        """out[r, j] = vals[src[r * cols + j]] where src names a value, else 0; out: f32 [rows, cols] (view ok)"""
+        self._check(self._lib.fl_ep_gather_f32(vals.data_ptr(), vals.numel(), src.data_ptr(), out.data_ptr(), out.shape[0] * out.shape[1],
+                                               out.shape[1], self._rows2d(out, "out"), self._stream(out.device)), "fl_ep_gather_f32")
 
 
 class AllToAll:
@@ -117,7 +133,18 @@ class AllToAll:
         dist.all_to_all_single(out, inp, group=self.group)       # equal splits: world slabs of `cap` rows
         return out
 
-    def dispatch(self, out_exclusive_sum, out_expert_x, dp_x, indices, num_global_tokens):
+    def _message(self, dtype, device):
+        """one slab-row message buffer [S, hidden + tail] in the row dtype and its views: rows, ids (int32), weights (f32)"""
+        K = self.top_k
+        tail = (4 * K + 7) // 8 * 8                                # 2-byte elements behind the row: K int32 ids + K f32 weights, 16-B rounded
+        S = self.world * self.cap
+        msg = torch.empty(S, self.hidden + tail, dtype=dtype, device=device)
+        h2 = self.hidden // 2
+        return msg, msg[:, :self.hidden], msg.view(torch.int32)[:, h2:h2 + K], msg.view(torch.float32)[:, h2 + K:h2 + 2 * K]
+
+    def dispatch(self, out_exclusive_sum, out_expert_x, dp_x, indices, num_global_tokens, weights=None):
+        """`weights` (optional, an extension over fast_ep.py:45-51): the routing weights [tokens, top_k] of the SAME step — they then
+        travel in the dispatch message and `combine` needs no message of its own for them (one all-to-all per direction)."""
         t = dp_x.shape[0]
         # (the kernels copy 2-byte rows and read int32 ids whatever the tensors claim to be: check before marshalling)
         if indices.dtype != torch.int32:
@@ -130,40 +157,47 @@ class AllToAll:
             raise RuntimeError("AllToAll: hidden must be a multiple of 8")
         if t > self.max_tokens_per_rank:
             raise RuntimeError(f"{t} local tokens exceed the capacity {self.max_tokens_per_rank} this AllToAll was built for")
+        if weights is not None and weights.numel() != t * self.top_k:
+            raise RuntimeError("AllToAll.dispatch: weights must hold tokens x top_k values")
         dev, W, K = dp_x.device, self.world, self.top_k
         S = W * self.cap
         idx = indices.reshape(-1).contiguous()
         tok_slot = torch.empty(t * W, dtype=torch.int32, device=dev)
         pair_src = torch.empty(S * K, dtype=torch.int32, device=dev)
-        send_eid = torch.empty(S * K, dtype=torch.int32, device=dev)
+        msg, send_rows, send_eid, send_w = self._message(dp_x.dtype, dev)
         self.row_ops.route_dedup(idx, K, self.experts_per_rank, W, self.cap, tok_slot, send_eid, pair_src)
-        send_buf = torch.empty(S, self.hidden, dtype=dp_x.dtype, device=dev)   # empty rows: never read (all their eids are -1)
-        self.row_ops.send(dp_x.contiguous(), tok_slot, W, send_buf)
-        recv_buf = self._a2a(send_buf)
-        recv_eid = self._a2a(send_eid)
+        self.row_ops.send(dp_x.contiguous(), tok_slot, W, send_rows)              # empty rows: never read (all their ids are -1)
+        if weights is not None:
+            self.row_ops.gather_f32(weights.to(torch.float32).reshape(-1).contiguous(), pair_src, send_w)
+        recv = self._a2a(msg)                                                     # ONE message: rows + ids (+ weights)
+        h2 = self.hidden // 2
+        recv_rows, recv_eid = recv[:, :self.hidden], recv.view(torch.int32)[:, h2:h2 + K]
+        recv_w = recv.view(torch.float32)[:, h2 + K:h2 + 2 * K] if weights is not None else None
         # received (row, j) pairs grouped by local expert; a row with several local experts is replicated HERE
         order = torch.empty(S * K, dtype=torch.int32, device=dev)
         inv = torch.empty(S * K, dtype=torch.int32, device=dev)      # position of every received pair in the sorted rows (combine)
         self.row_ops.sort(recv_eid, self.experts_per_rank, order, out_exclusive_sum, inv)
         n_out = min(out_expert_x.shape[0], S * K)
         # (static launch over the row bound; only the rows below exclusive_sum[-1] — a device value — are copied)
-        self.row_ops.gather_div(recv_buf, order, n_out, K, out_expert_x, out_exclusive_sum[self.experts_per_rank:])
-        self._state = (tok_slot, pair_src, inv, n_out, S)
+        self.row_ops.gather_div(recv_rows, order, n_out, K, out_expert_x, out_exclusive_sum[self.experts_per_rank:])
+        self._state = (tok_slot, pair_src, inv, n_out, S, recv_w)
         return out_expert_x, out_exclusive_sum
 
     def combine(self, out_tokens, weights, expert_y, num_global_tokens):
         if self._state is None:
             raise RuntimeError("combine() without a preceding dispatch()")
-        tok_slot, pair_src, inv, n_out, S = self._state
+        tok_slot, pair_src, inv, n_out, S, recv_w = self._state
         dev, W, K = expert_y.device, self.world, self.top_k
         if expert_y.element_size() != 2 or expert_y.shape[1] != self.hidden:
             raise RuntimeError(f"AllToAll.combine: expert_y must be a 2-byte [rows, {self.hidden}] tensor")
         if weights.numel() != out_tokens.shape[0] * K:
             raise RuntimeError("AllToAll.combine: weights must hold tokens x top_k values")
-        # the pairs' weights travel to the expert ranks in the layout of the expert ids (0 where a row has no j-th expert)
-        send_w = torch.empty(S * K, dtype=torch.float32, device=dev)
-        self.row_ops.gather_f32(weights.to(torch.float32).reshape(-1).contiguous(), pair_src, send_w)
-        recv_w = self._a2a(send_w)
+        if recv_w is None:
+            # the weights did not travel with the dispatch (the reference's call order): they go to the expert ranks now, in the
+            # layout of the expert ids (0 where a row has no j-th expert)
+            send_w = torch.empty(S, K, dtype=torch.float32, device=dev)
+            self.row_ops.gather_f32(weights.to(torch.float32).reshape(-1).contiguous(), pair_src, send_w)
+            recv_w = self._a2a(send_w)
         # expert rank: ONE row per received token = weighted sum over its local experts (rows nobody computed — pairs beyond
         # expert_y — and empty slab rows contribute nothing: their weight is 0 / their position is out of range)
         back = torch.empty(S, self.hidden, dtype=expert_y.dtype, device=dev)

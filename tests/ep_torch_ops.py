@@ -25,13 +25,14 @@ class TorchRowOps:
                     d = e // experts_per_rank
                     row = ts[t][d]
                     if row >= 0:
-                        send_eid[row * top_k + seen[d]] = e - d * experts_per_rank
+                        send_eid[row, seen[d]] = e - d * experts_per_rank      # [rows, top_k] (possibly a view into the message tail)
                         pair_src[row * top_k + seen[d]] = t * top_k + k
                     seen[d] += 1
         if T:
             tok_slot.copy_(torch.tensor(ts, dtype=torch.int32).view(-1))
 
     def sort(self, recv_eid, E, order, exclusive_sum, inverse=None):
+        recv_eid = recv_eid.reshape(-1)                          # [rows, top_k] (view ok) -> the flattened (row, j) pairs
         key = torch.where((recv_eid >= 0) & (recv_eid < E), recv_eid, torch.full_like(recv_eid, E))
         order.copy_(torch.argsort(key, stable=True).to(torch.int32))
         counts = torch.bincount(key.long(), minlength=E + 1)[:E]
@@ -61,4 +62,4 @@ class TorchRowOps:
 
     def gather_f32(self, vals, src, out):
         ok = (src >= 0) & (src < vals.numel())
-        out.copy_(torch.where(ok, vals[src.clamp(0, max(vals.numel() - 1, 0)).long()] if vals.numel() else torch.zeros(src.numel()), torch.zeros(())))
+        out.copy_(torch.where(ok, vals[src.clamp(0, max(vals.numel() - 1, 0)).long()] if vals.numel() else torch.zeros(src.numel()), torch.zeros(())).view(out.shape))

@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, t_per_rank, one_peer=False):
+def _worker(rank, world, port, t_per_rank, one_peer=False, weights_at_dispatch=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "sglang-fluentllm_amd"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -41,7 +41,12 @@ def _worker(rank, world, port, t_per_rank, one_peer=False):
         assert a2a.cap == max(t_per_rank) and a2a.slab_bytes() == world * max(t_per_rank) * HID * 2   # one row per (token, peer)
         ex = torch.empty(E // world + 1, dtype=torch.int32)
         expert_x = torch.zeros(T_g * K, HID, dtype=torch.bfloat16)
-        a2a.dispatch(out_exclusive_sum=ex, out_expert_x=expert_x, dp_x=x, indices=idx, num_global_tokens=T_g)
+        sent = []
+        orig_a2a = a2a._a2a
+        a2a._a2a = lambda inp: (sent.append(tuple(inp.shape)), orig_a2a(inp))[1]      # count the messages of each direction
+        a2a.dispatch(out_exclusive_sum=ex, out_expert_x=expert_x, dp_x=x, indices=idx, num_global_tokens=T_g,
+                     **({"weights": w} if weights_at_dispatch else {}))
+        assert len(sent) == 1 and sent[0][1] == HID + 16, sent                          # ONE dispatch message: row + 3 ids + 3 weights, 16-B rounded
         # exclusive_sum consistent with what every rank routed to my experts
         all_idx = [None] * world
         dist.all_gather_object(all_idx, idx.tolist())
@@ -55,6 +60,7 @@ def _worker(rank, world, port, t_per_rank, one_peer=False):
             y[lo:hi] = (expert_x[lo:hi].float() * (rank * (E // world) + le + 1)).to(torch.bfloat16)
         out = torch.empty(t, HID, dtype=torch.bfloat16)
         a2a.combine(out_tokens=out, weights=w, expert_y=y, num_global_tokens=T_g)
+        assert len(sent) == (2 if weights_at_dispatch else 3), sent                     # combine: rows back (+ the weights if they did not travel yet)
         ref = sum(w[:, k:k + 1] * (x.float() * (idx[:, k:k + 1].float() + 1)).to(torch.bfloat16).float() for k in range(K)).to(torch.bfloat16) if t else out
         assert torch.allclose(out.float(), ref.float(), atol=2e-2, rtol=2e-2), float((out.float() - ref.float()).abs().max())
         # bench.py's reduction: step time = MAX over ranks
@@ -69,6 +75,12 @@ def _worker(rank, world, port, t_per_rank, one_peer=False):
 def test_ep_all_to_all_world2_gloo(t_per_rank):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, t_per_rank), nprocs=2, join=True)
+
+
+def test_ep_all_to_all_world2_gloo_weights_travel_with_the_dispatch():
+    """dispatch(..., weights=): ids AND routing weights in the slab-row tail -> one all-to-all per direction"""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, [5, 7], False, True), nprocs=2, join=True)
 
 
 def test_ep_all_to_all_world2_gloo_every_token_to_one_peer():

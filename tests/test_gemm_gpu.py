@@ -377,9 +377,12 @@ def test_ep_all_to_all_single_rank_hip_row_ops():
     assert torch.allclose(out.cpu().float(), ref.float(), atol=2e-2, rtol=2e-2)
 
 
-def test_ep_dedup_row_kernels_match_the_torch_row_ops_world4_routing():
-    """The token-once-per-peer routing kernels (route_dedup / gather_f32 / sort with inverse / gather_div) against the torch-indexing
-    implementation the gloo tests inject, with the routing of a 4-rank job (no exchange needed to compare the kernels)."""
+@pytest.mark.parametrize("layout", ["dense", "message_tail"])
+def test_ep_dedup_row_kernels_match_the_torch_row_ops_world4_routing(layout):
+    """The token-once-per-peer routing kernels (route_dedup / gather_f32 / sort with inverse / gather_div / send) against the
+    torch-indexing implementation the gloo tests inject, with the routing of a 4-rank job (no exchange needed to compare the
+    kernels) — on dense [rows, top_k] tensors and on VIEWS into a slab-row message [rows, hidden | ids | weights] (the
+    single-message dispatch: the kernels take row strides)."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -389,39 +392,53 @@ def test_ep_dedup_row_kernels_match_the_torch_row_ops_world4_routing():
     hip, ref = HipRowOps(), TorchRowOps()
     W, EPR, K, T, HID = 4, 8, 8, 53, 128
     cap = 40                                                   # < T on purpose: rows past the slab end are dropped the same way
+    S = W * cap
     g = torch.Generator().manual_seed(77)
     idx = torch.stack([torch.randperm(W * EPR, generator=g)[:K] for _ in range(T)]).to(torch.int32)
     idx[3, 2] = -1                                              # an invalid id is ignored by both
+    x = torch.randn(T, HID, generator=torch.Generator().manual_seed(8)).to(torch.bfloat16)
     outs = []
     for ops, dev in ((ref, "cpu"), (hip, DEV)):
         ts = torch.empty(T * W, dtype=torch.int32, device=dev)
-        pp = torch.empty(W * cap * K, dtype=torch.int32, device=dev)   # pair_src: the (token, k) behind every slab pair
-        se = torch.empty(W * cap * K, dtype=torch.int32, device=dev)
+        pp = torch.empty(S * K, dtype=torch.int32, device=dev)   # pair_src: the (token, k) behind every slab pair
+        if layout == "dense":
+            rows = torch.zeros(S, HID, dtype=torch.bfloat16, device=dev)
+            se = torch.empty(S, K, dtype=torch.int32, device=dev)
+            placed = torch.empty(S, K, dtype=torch.float32, device=dev)
+        else:
+            msg = torch.zeros(S, HID + 4 * K, dtype=torch.bfloat16, device=dev)
+            rows, se = msg[:, :HID], msg.view(torch.int32)[:, HID // 2:HID // 2 + K]
+            placed = msg.view(torch.float32)[:, HID // 2 + K:HID // 2 + 2 * K]
         ops.route_dedup(idx.to(dev).reshape(-1), K, EPR, W, cap, ts, se, pp)
+        ops.send(x.to(dev), ts, W, rows)
         vals = torch.rand(T * K, generator=torch.Generator().manual_seed(5)).to(dev)
-        placed = torch.empty(W * cap * K, dtype=torch.float32, device=dev)
         ops.gather_f32(vals, pp, placed)
-        order = torch.empty(W * cap * K, dtype=torch.int32, device=dev)
+        order = torch.empty(S * K, dtype=torch.int32, device=dev)
         ex = torch.empty(EPR + 1, dtype=torch.int32, device=dev)
-        inv = torch.full((W * cap * K,), -1, dtype=torch.int32, device=dev)
+        inv = torch.full((S * K,), -1, dtype=torch.int32, device=dev)
         ops.sort(se, EPR, order, ex, inv)
-        src = torch.randn(W * cap, HID, generator=torch.Generator().manual_seed(6)).to(torch.bfloat16).to(dev)
         n = int(ex[-1])
-        dst = torch.zeros(W * cap * K, HID, dtype=torch.bfloat16, device=dev)
-        ops.gather_div(src, order, W * cap * K, K, dst, ex[EPR:])      # static launch over the row bound, device-side row count
+        dst = torch.zeros(S * K, HID, dtype=torch.bfloat16, device=dev)
+        ops.gather_div(rows, order, S * K, K, dst, ex[EPR:])           # static launch over the row bound, device-side row count
         assert bool((dst[n:] == 0).all())                               # rows past exclusive_sum[-1] are not touched
         dst = dst[:n]
-        outs.append([t.cpu() for t in (ts, pp, se, placed, ex)])
+        outs.append([t.cpu().contiguous() for t in (ts, pp, se, placed, ex, rows)])
         # the order INSIDE an expert group is free (the device sort hands positions out with atomics): check it by meaning
-        o, sec, exc = order.cpu().long(), se.cpu(), ex.cpu()
-        assert sorted(o.tolist()) == list(range(W * cap * K))
+        o, sec, exc = order.cpu().long(), se.cpu().reshape(-1), ex.cpu()
+        assert sorted(o.tolist()) == list(range(S * K))
         for e in range(EPR):
             assert bool((sec[o[int(exc[e]):int(exc[e + 1])]] == e).all())
         assert bool((sec[o[n:]] < 0).all())
-        assert torch.equal(inv.cpu().long()[o], torch.arange(W * cap * K))
-        assert torch.equal(dst.cpu(), src.cpu()[o[:n] // K])
-    for a, b in zip(*outs):                                     # slab positions are handed out in token order by both
-        assert torch.equal(a, b)
+        assert torch.equal(inv.cpu().long()[o], torch.arange(S * K))
+        assert torch.equal(dst.cpu(), rows.cpu()[o[:n] // K])
+        # weighted return with the weights read through the (possibly strided) view
+        back = torch.empty(S, HID, dtype=torch.bfloat16, device=dev)
+        y = torch.full((S * K, HID), 2.0, dtype=torch.bfloat16, device=dev)   # (position-free values: the order inside a group differs between the two)
+        ops.combine(y, inv, placed, back, K)
+        outs[-1].append(back.float().cpu())
+    for a, b in zip(outs[0][:-1], outs[1][:-1]):               # slab positions are handed out in token order by both
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b)
+    assert torch.allclose(outs[0][-1], outs[1][-1], rtol=1e-2, atol=1e-2)   # expert-side weighted sums through the weight view
 
 
 def test_masked_big_tile_vs_oracle():

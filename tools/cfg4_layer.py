@@ -102,7 +102,8 @@ def build(dev, world, rank, group, layers, seq=SEQ, bs=BS, seed=0):
         logits = flashinfer.dsv3_router_gemm(B["norm2"], w["router"], out_dtype=torch.float32)   # B1: bf16 MFMA kernel (csrc/bmm_bf16.hip)
         tw, ti = flashinfer.moe_fused_gate(logits, w["bias"], N_GROUP, TOPK_GROUP, TOPK, routed_scaling_factor=2.5)
         B["logits"], B["topk_w"], B["topk_ids"] = logits, tw, ti
-        a2a.dispatch(out_exclusive_sum=B["ex"], out_expert_x=B["xrows"], dp_x=B["norm2"], indices=ti, num_global_tokens=bs)
+        # (the routing weights travel in the dispatch message: one all-to-all per direction)
+        a2a.dispatch(out_exclusive_sum=B["ex"], out_expert_x=B["xrows"], dp_x=B["norm2"], indices=ti, num_global_tokens=bs, weights=tw)
         flashinfer.quantization.quant_1x128(B["xrows"], B["xq"], B["xs"], B["ex"], el, (rows + 3) // 4 * 4, mp, HID)
         deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset((B["xq"], B["xs"]), w["w13"], B["gate_up"], B["ex"], use_pdl=True)
         act = silu(B["gate_up"], B["ex"], rows)
@@ -119,13 +120,13 @@ def build(dev, world, rank, group, layers, seq=SEQ, bs=BS, seed=0):
     w_bytes = sum(W[0][k][0].numel() for k in ("qkv_a", "o", "w13", "w2"))
     xgmi = {  # bytes this rank SENDS per layer (bf16 rows), by collective
         "allgather": (world - 1) * t_loc * HID * 2, "reducescatter": (world - 1) * t_loc * HID * 2,
-        "ep_dispatch": (world - 1) * (a2a.cap * HID * 2 + a2a.cap * TOPK * 4),
-        "ep_combine": (world - 1) * (a2a.cap * HID * 2 + a2a.cap * TOPK * 4)}
+        "ep_dispatch": (world - 1) * a2a.cap * (HID * 2 + TOPK * 8),   # row + top_k ids + top_k weights in the row tail
+        "ep_combine": (world - 1) * a2a.cap * HID * 2}
     info = dict(bs=bs, seq=seq, heads_per_rank=h, experts_per_rank=el, tokens_per_rank=t_loc, routed_row_bound=rows,
                 ep_slab_rows_per_peer=a2a.cap, kv_bytes_per_layer=kv_bytes, weight_bytes_per_layer=w_bytes,
                 xgmi_send_bytes_per_layer=xgmi,
                 comm_route={"allgather / reducescatter (<= 1024 tokens)": "one-shot peer-mapped kernel" if getattr(h_tp[0], "oneshot", None) is not None
-                            else "RCCL collective + fused kernel", "ep_dispatch / ep_combine": "RCCL all_to_all_single"})
+                            else "RCCL collective + fused kernel", "ep_dispatch / ep_combine": "ONE RCCL all_to_all_single each (ids + weights in the slab-row tail)"})
     # everything a checker needs to recompute the layer from its inputs (tests/test_cfg4_gpu.py); not used by the bench
     info["_state"] = dict(W=W, B=B, wl=wl, hid_loc=hid_loc, attn_o=attn_o, meta=meta, ns=ns, res_in=B["res"].clone())
     return step, info
