@@ -994,10 +994,11 @@ int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipSt
     const char* e = getenv("FLUENT_MLA_MERGE_KERNEL");
     return (e == nullptr || e[0] == '\0') ? -1 : (e[0] == '1' ? 1 : 0);
   }();
-  // in-kernel merge when splits are rare (at least as many requests as parts: a part boundary splits at most one
-  // request, typically into 2-3 pieces); with fewer requests than parts EVERY request is cut into many pieces and the
-  // row-parallel merge kernel is the better tool
-  p.merge_in_kernel = (p.row_groups <= 6 && (merge_env == 0 || (merge_env < 0 && p.bs >= p.num_parts))) ? 1 : 0;
+  // in-kernel merge when a request is cut into few pieces (at least half as many requests as parts: 2-3 pieces each); with
+  // fewer requests EVERY request is cut into many pieces and the row-parallel merge kernel is the better tool.  Measured
+  // (tools/bench_one_batch.py, 61-layer step, seq 4096, H = 128): bs = 64 (2 pieces) 4.38-4.41 ms in-kernel vs 4.46 with the merge
+  // kernel; bs = 32 (4 pieces) 3.23 vs 2.99; bs = 16 3.00 vs 2.32; bs = 1 4.55 vs 1.79
+  p.merge_in_kernel = (p.row_groups <= 6 && (merge_env == 0 || (merge_env < 0 && 2 * p.bs >= p.num_parts))) ? 1 : 0;
   const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(512);
   if (a->kv_format == FL_KV_FP8_576)
     mla_decode_y_kernel<1><<<grid, block, 0, stream>>>(
