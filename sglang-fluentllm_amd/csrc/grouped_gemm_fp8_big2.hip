@@ -16,8 +16,9 @@
 //   * TWO WAVE GROUPS IN ANTI-PHASE: waves 0-3 (token half 0) and 4-7 (token half 1) share the four SIMDs pairwise and
 //     run half a step apart, separated by workgroup barriers: while one wave of a SIMD issues its 8 MFMAs (segment M),
 //     its partner issues LDS-DMA, reads operands and rescales (segment L).  Intervals:
-//         X:  L0 | M0 | L1 | M1 | ...            (barrier between all segments; Y executes one barrier more up front,
-//         Y:     | L0 | M0 | L1 | M1 | ...        X one more at the end)
+//         X:  L0 | M0 | L1 | M1 | ...            (a barrier between all segments; Y executes one barrier more
+//         Y:     | L0 | M0 | L1 | M1 | ...        up front, X one more at the end.  FL_GEMM2_ONEBAR=1 (experiment, slower): only the
+//                                                 barriers in front of X's L segments — X runs L(h) M(h), Y runs M(h-1) L(h) per step)
 //   * XCD-aware tile order: the 32 workgroups of an XCD in one round take 32 CONSECUTIVE tiles (n fastest): the tiles of
 //     one 512-row expert (2 x 16 tiles of w13) share their W and A panels through ONE L2.
 #include "grouped_gemm_shared.h"
@@ -71,6 +72,11 @@ __device__ __forceinline__ void mfma_acc(v16f& acc, const v8i a, const v8i b, co
 #define FL_GEMM2_XTILE 1      // the refill crosses tile boundaries (0: every tile starts with a cold three-stage prologue).  Measured
                               // (profiles/r03_gemm_big2_xtile_ab.txt): w13 -0.4 %, w2 +1.4 % — the kernel is power-capped; kept for the
                               // short-k shapes (w2: 16 k blocks per tile) and because this form allocates without scratch (the 0 form: 8 B)
+#endif
+#ifndef FL_GEMM2_ONEBAR
+#define FL_GEMM2_ONEBAR 0     // experiment (parity-green, measured SLOWER: w13 -2.5 %, w2 -3.5 %, profiles/r03_gemm_big2_onebar_ab.txt): ONE
+                              // barrier per half step — the barrier between a step's two intervals (X: L | M, Y: M | L) dropped; nothing
+                              // is handed over there, but without it the two groups' M segments overlap in time and the step gets longer
 #endif
 #ifndef FL_GEMM2_PRIO
 #define FL_GEMM2_PRIO 0   // measured (profiles/r03_gemm_big2_variants_ab.txt): +2 % without the priority flips
@@ -348,7 +354,9 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     GT(3);
     seg_load(h, true, first);
     GT(0);
-    G2_BARRIER();
+    // (k block 0 keeps this barrier: its M segment issues stage 3 into the slot that was the PREVIOUS tile's epilogue staging area,
+    //  and group Y passes this barrier only after its own epilogue)
+    if (!FL_GEMM2_ONEBAR || first) G2_BARRIER();
     GT(3);
     seg_mma(h, true, first);
     GT(1);
@@ -360,14 +368,14 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     GT(3);
     seg_load(h + 1, false, false);
     GT(0);
-    G2_BARRIER();
+    if (!FL_GEMM2_ONEBAR) G2_BARRIER();
     GT(3);
     seg_mma(h + 1, false, false);
   };
   auto kblock_y = [&](const int kb, const bool first) __attribute__((always_inline)) {
     const int h = 2 * kb;
     GT(1);
-    G2_BARRIER();
+    if (!FL_GEMM2_ONEBAR || first) G2_BARRIER();
     GT(3);
     seg_load(h, true, first);
     // reads of slot h complete (group X refills it right after the next barrier) + this wave's pieces of stage h + 1:
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     GT(3);
     seg_mma(h, true, first);
     GT(1);
-    G2_BARRIER();
+    if (!FL_GEMM2_ONEBAR) G2_BARRIER();
     GT(3);
     seg_load(h + 1, false, false);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
