@@ -859,10 +859,29 @@ __global__ __launch_bounds__(256) void mla_combine_kernel(const Params p, const 
   }
 }
 
+// few rows, many splits per row (decode at bs = 1..8): ONE row per workgroup, its splits over the four waves (combine_row QUAD)
+__global__ __launch_bounds__(256) void mla_combine_quad_kernel(const Params p, const int32_t* __restrict__ g_num_splits) {
+  __shared__ float red[3 * 64 * 10];
+  if (g_num_splits[p.bs] == p.bs) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int req = (int)(blockIdx.x / p.rows), row = (int)(blockIdx.x % p.rows);
+  const int s0 = g_num_splits[req], ns = g_num_splits[req + 1] - s0;
+  if (ns <= 1) return;   // (uniform over the workgroup)
+  combine_row<0, true>(p, req, row, s0, ns, lane, red, wave);
+}
+
 }  // namespace
 
 int fl_mla_launch_combine(const Params& p, const int32_t* num_splits, hipStream_t stream) {
   const long long waves = (long long)p.bs * p.rows;
+  // (requests x rows) below one wave per SIMD of the chip AND more parts than requests x 8 (every request is cut into many
+  // pieces — the split counts themselves live on the device): a workgroup per row
+  if (waves <= 1024 && p.num_parts >= 8 * p.bs) {
+    mla_combine_quad_kernel<<<dim3((unsigned)waves), dim3(256), 0, stream>>>(p, num_splits);
+    FL_CHECK_LAUNCH("mla_combine_quad_kernel");
+    return FL_OK;
+  }
   const long long blocks = (waves + 3) / 4;   // one wave per (request, row); grid-stride beyond 2048 workgroups
   mla_combine_kernel<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream>>>(p, num_splits);
   FL_CHECK_LAUNCH("mla_combine_kernel");

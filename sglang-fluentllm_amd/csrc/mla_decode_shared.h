@@ -52,15 +52,34 @@ __device__ __forceinline__ v8i make_v8i(uint4 a, uint4 b) {
 // split-KV merge of one (request, row): out[req,row,:] = sum_s w_s * o_accum[slot_s,row,:], w_s = softmax_s(weight LSE_s);
 // reported lse from the exact LSEs.  One wave per row, lane = 8 consecutive dims.
 // NS > 0: compile-time split count (all loads of a row are independent and issued together); NS = 0: run-time count.
-template <int NS>
+// QUAD (NS = 0 only): the four waves of a workgroup share ONE row — wave w accumulates splits [w q, (w + 1) q), q = ceil(ns / 4), against
+// the common maxima, wave 0 adds the partial sums of waves 1..3 (through `red`, [3][64][10] floats) in wave order and writes: with a
+// handful of rows and dozens of splits per row (decode at bs = 1..8) a wave per row is a chain of ns / 8 memory round trips on a
+// mostly empty chip (8.7 us per launch at bs = 1, 64 splits: round 3)
+template <int NS, bool QUAD = false>
 __device__ __forceinline__ void combine_row(const Params& p, const int req, const int row, const int s0, const int ns_rt,
-                                            const int lane) {
+                                            const int lane, float* red = nullptr, const int wave = 0) {
   const int ns = NS > 0 ? NS : ns_rt;
   float mx = -INFINITY, mxx = -INFINITY;
+  if (NS > 0) {
 #pragma unroll
-  for (int s = 0; s < ns; ++s) {
-    mx = fmaxf(mx, p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 0]);
-    mxx = fmaxf(mxx, p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 1]);
+    for (int s = 0; s < ns; ++s) {
+      mx = fmaxf(mx, p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 0]);
+      mxx = fmaxf(mxx, p.lse_accum[((long long)(s0 + s) * p.rows + row) * 2 + 1]);
+    }
+  } else {
+    // run-time split count (up to 64 and more at small batch): lane l looks at splits l, l + 64, ..., then a wave maximum — one
+    // memory round trip instead of `ns` of them (round 3: the merge kernel at bs = 1, 64 splits per row)
+    for (int s = lane; s < ns; s += 64) {
+      const float2 v = *reinterpret_cast<const float2*>(p.lse_accum + ((long long)(s0 + s) * p.rows + row) * 2);
+      mx = fmaxf(mx, v.x);
+      mxx = fmaxf(mxx, v.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, o));
+      mxx = fmaxf(mxx, __shfl_xor(mxx, o));
+    }
   }
   float den = 0.f, denx = 0.f;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -68,12 +87,18 @@ __device__ __forceinline__ void combine_row(const Params& p, const int req, cons
   // up to 64 would otherwise be that many dependent round trips per row)
   constexpr int kChunk = NS > 0 ? NS : 8;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  for (int c0 = 0; c0 < ns; c0 += kChunk) {
+  int c_lo = 0, c_hi = ns;
+  if (QUAD) {
+    const int per = (ns + 3) / 4;
+    c_lo = wave * per < ns ? wave * per : ns;
+    c_hi = c_lo + per < ns ? c_lo + per : ns;
+  }
+  for (int c0 = c_lo; c0 < c_hi; c0 += kChunk) {
     u32x4 ua[kChunk], ub[kChunk];
     float ls[kChunk], lx[kChunk];
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
-      const int s = c0 + j < ns ? c0 + j : ns - 1;   // (unconditional loads; the tail is weighted 0 below)
+      const int s = c0 + j < c_hi ? c0 + j : c_hi - 1;   // (unconditional loads; the tail is weighted 0 below)
       const long long base = (long long)(s0 + s) * p.rows + row;
       ls[j] = p.lse_accum[base * 2 + 0];
       lx[j] = p.lse_accum[base * 2 + 1];
@@ -86,7 +111,7 @@ __device__ __forceinline__ void combine_row(const Params& p, const int req, cons
     }
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
-      const bool live = c0 + j < ns;
+      const bool live = c0 + j < c_hi;
       const float wgt = (!live || mx == -INFINITY) ? 0.f : __expf(ls[j] - mx);
       den += wgt;
       denx += (!live || mxx == -INFINITY) ? 0.f : __expf(lx[j] - mxx);
@@ -102,6 +127,25 @@ __device__ __forceinline__ void combine_row(const Params& p, const int req, cons
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] += wgt * f[i];
       }
+    }
+  }
+  if (QUAD) {
+    if (wave > 0) {
+      float* r = red + ((wave - 1) * 64 + lane) * 10;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r[i] = acc[i];
+      r[8] = den;
+      r[9] = denx;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const float* r = red + (w * 64 + lane) * 10;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += r[i];
+      den += r[8];
+      denx += r[9];
     }
   }
   const float inv = den > 0.f ? 1.f / den : 0.f;
