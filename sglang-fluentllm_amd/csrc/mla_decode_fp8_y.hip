@@ -875,11 +875,16 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const float lseq_nat = lq > 0.f ? (__builtin_amdgcn_logf(lq) + m_o - kPShift) * 0.6931471805599453f : -INFINITY;
     const int slot_idx = split_base + split_idx;
     if (row_ok && lh == 0 && W == 0) {
+      // (the row index is made opaque HERE: derived 64-bit offsets — row / h_q, the LSE slots — are otherwise formed before the page
+      //  loop and spilled across it)
+      unsigned row_e = (unsigned)row;
+      asm volatile("" : "+v"(row_e));
       if (is_split) {   // (agent-scope stores: read by whichever part merges the request, see the merge below)
-        st_agent_f32(p.lse_accum + ((long long)slot_idx * p.rows + row) * 2 + 0, lseq_nat);
-        st_agent_f32(p.lse_accum + ((long long)slot_idx * p.rows + row) * 2 + 1, lse_nat);
+        float* la = p.lse_accum + (long long)slot_idx * p.rows * 2;
+        st_agent_f32(la + row_e * 2u + 0, lseq_nat);
+        st_agent_f32(la + row_e * 2u + 1, lse_nat);
       } else {
-        const int j = row / p.h_q, h = row - j * p.h_q;
+        const unsigned j = row_e / (unsigned)p.h_q, h = row_e - j * (unsigned)p.h_q;
         p.lse[((long long)req * p.h_q + h) * p.s_q + j] = lse_nat;
       }
     }
@@ -892,6 +897,20 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       const int row0 = rgrp * 64 + rt * 32;
       uint16_t* dst = is_split ? reinterpret_cast<uint16_t*>(p.o_accum) + ((long long)slot_idx * p.rows + row0) * kDN
                                : p.out + ((long long)req * p.rows + row0) * kDN;
+#ifndef FL_Y_EPI_SADDR
+#define FL_Y_EPI_SADDR 1   // the epilogue's 8 row addresses as ONE uniform base (SGPR pair, pinned behind the page loop) + 32-bit lane
+                           // offsets: hipcc otherwise forms eight 64-bit row pointers BEFORE the page loop (they depend on the request
+                           // only) and, with the PV wave at 256 registers, spills them — 14 scratch stores in the request prologue,
+                           // ~40 dependent scratch reloads in the epilogue (104 B of scratch per lane: VERDICT r2 item 3d)
+#endif
+#if FL_Y_EPI_SADDR
+      {
+        unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)dst);
+        unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)dst >> 32));
+        asm volatile("" : "+s"(lo), "+s"(hi));   // (computed HERE, after the loop)
+        dst = reinterpret_cast<uint16_t*>(((unsigned long long)hi << 32) | lo);
+      }
+#endif
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -903,7 +922,12 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
                 make_float4(o[4 * c + jq][g * 4 + 0] * inv, o[4 * c + jq][g * 4 + 1] * inv,
                             o[4 * c + jq][g * 4 + 2] * inv, o[4 * c + jq][g * 4 + 3] * inv);
           }
+#if FL_Y_EPI_SADDR
+        unsigned voff = (unsigned)(256 * W + 128 * c + (lane & 15) * 8 + (lane >> 4) * kDN);   // elements; row r = (lane >> 4) + 4 k: + 4 k kDN
+        asm volatile("" : "+v"(voff));
+#else
         uint16_t* dbase = dst + 256 * W + 128 * c + (lane & 15) * 8;
+#endif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int r = (lane >> 4) + 4 * k;
@@ -915,8 +939,13 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           ov.z = fl_pack_bf16(v1.x, v1.y);
           ov.w = fl_pack_bf16(v1.z, v1.w);
           if (row0 + r < p.rows) {
-            if (is_split) st_agent_16B(dbase + (long long)r * kDN, ov);
-            else *reinterpret_cast<uint4*>(dbase + (long long)r * kDN) = ov;
+#if FL_Y_EPI_SADDR
+            uint16_t* ptr = dst + (voff + (unsigned)(4 * k * kDN));
+#else
+            uint16_t* ptr = dbase + (long long)r * kDN;
+#endif
+            if (is_split) st_agent_16B(ptr, ov);
+            else *reinterpret_cast<uint4*>(ptr) = ov;
           }
         }
       }
