@@ -592,9 +592,11 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
   auto load_window = [&](int base) {                                                                                   \
     win_base = base;                                                                                                   \
     const int t = base + lane;                                                                                         \
-    int pg = 0;                                                                                                        \
-    if (t < n) pg = g_block_table[(long long)req * p.bt_stride + tile_b + t];                                          \
-    pg_vec = (pg < 0 || pg >= p.num_pages) ? 0 : pg;                                                                   \
+    /* UNCONDITIONAL load on an index clamped into the request's table row: the load does not wait for the sequence  */ \
+    /* length (n) — at a request's start both go out together, one memory round trip less in the prologue chain       */ \
+    const long long col = tile_b + t < p.bt_stride ? tile_b + t : p.bt_stride - 1;                                     \
+    const int pg = g_block_table[(long long)req * p.bt_stride + (col < 0 ? 0 : col)];                                  \
+    pg_vec = (t >= n || pg < 0 || pg >= p.num_pages) ? 0 : pg;                                                         \
   };                                                                                                                   \
   load_window(0);                                                                                                      \
   auto page_of = [&](int t) { return (long long)__builtin_amdgcn_readlane(pg_vec, t - win_base); }
