@@ -11,10 +11,14 @@ DEV = "cuda:0"
 
 @pytest.mark.parametrize("T,H,neox", [(1, 16, False), (37, 16, False), (128, 128, False), (300, 16, True), (129, 32, False)])
 def test_fused_absorb_rope_quant_is_bit_identical_to_the_four_launch_chain(T, H, neox):
+    import os
+
     import flash_mla_fp8 as fm
     from fluent_mi355.bmm import bmm
     from fluent_mi355.rope import apply_rope_with_cos_sin_cache_inplace
 
+    if os.environ.get("FLUENT_BMM_WLDS", "") == "0":
+        pytest.skip("the fused launch repeats the B2 kernel's accumulation order; with FLUENT_BMM_WLDS=0 the chain's bmm is B1 (another k order)")
     g = torch.Generator().manual_seed(7 * T + H)
     q = (torch.randn(T, H, 192, generator=g) * torch.exp(torch.randn(T, H, 1, generator=g))).to(torch.bfloat16).to(DEV)
     w = (torch.randn(H, 512, 128, generator=g) * 0.05).to(torch.bfloat16).to(DEV)      # k-contiguous storage
