@@ -27,6 +27,7 @@ LAYERS = 61
 BS, SEQ, H, S_Q = 128, 4096, 128, 1
 SCALE = 192 ** -0.5
 FUSED_QUANT = os.environ.get("FLUENT_BENCH_FUSED_QUANT", "1") != "0"
+K4_IN_K1 = os.environ.get("FLUENT_BENCH_K4_IN_K1", "0") == "1"   # experiment switch, see layer_call
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling ~6290 GB/s
 
 
@@ -66,6 +67,10 @@ def build_workload(dev, layers, bs, seq, h, seed):
 def layer_call(fm, wl, l, meta, ns):
     k_lora, k_scale, k_rope = wl["caches"][l]
     pages = wl["pages"]
+    if K4_IN_K1:      # K5 alone, K4 inside K1's request prologue (flash_mla_fp8.flash_mla_ckv_fp8_per_token_bf16_q)
+        fm.quantize_and_cache_k(wl["k_new"], k_lora, k_scale, k_rope, wl["out_loc"], 512)
+        return fm.flash_mla_ckv_fp8_per_token_bf16_q(wl["q"], k_lora.view(pages, 64, 1, 512), k_rope.view(pages, 64, 1, 64),
+                                                     k_scale.view(pages, 64, 1, 1), wl["block_table"], wl["seqlens"], 512, meta, ns, SCALE, True)
     if FUSED_QUANT:   # K5 + K4 in one launch (flash_mla_fp8.quantize_q_and_cache_k): 2 launches per layer instead of 3
         qn, qs, qr = fm.quantize_q_and_cache_k(wl["q"], wl["k_new"], k_lora, k_scale, k_rope, wl["out_loc"], 512)
     else:             # the call sequence of the unmodified FlashMLABackend.forward_decode (flashmla_backend.py:188-206)

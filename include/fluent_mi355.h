@@ -139,6 +139,9 @@ typedef struct FlMlaDecodeArgs {
   float* o_accum;           /* split-KV workspace of (bs+num_parts)*s_q*h_q*d_nope*4 bytes (caller-owned, opaque:
                                f32 rows, or bf16 rows for the 128-row mapping; only fl_mla_decode reads it) */
   float* lse_accum;         /* f32 [bs+num_parts, s_q*h_q, 2] {weight LSE, exact LSE} workspace */
+  const void* q_bf16;       /* optional (FL_KV_FP8_PER_TOKEN, s_q*h_q > 32): the UNQUANTISED query bf16 [bs,s_q,h_q,576]; the decode
+                             * kernel then does quantize_ckv_per_token_head (K4, flashmla_backend.py:198-206) in its own prologue — same
+                             * bytes, same result, one launch and a write + re-read of Q less; q_nope / q_rope / q_scale are ignored */
 } FlMlaDecodeArgs;
 
 int fl_mla_decode(const FlMlaDecodeArgs* args, fl_stream_t stream);

@@ -913,9 +913,13 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   const bool per_token = a->kv_format == FL_KV_FP8_PER_TOKEN;
   FL_CHECK_ARG(a->d_nope == kDN && a->d_rope == kDR, "fl_mla_decode: only d_nope=512,d_rope=64 (got %d,%d)",
                a->d_nope, a->d_rope);
-  FL_CHECK_ARG(a->q_nope && a->k_nope, "fl_mla_decode: null q/k pointer");
-  FL_CHECK_ARG(!per_token || (a->q_rope && a->q_scale && a->k_rope && a->k_scale),
+  const bool q_bf16 = a->q_bf16 != nullptr;
+  FL_CHECK_ARG((q_bf16 || a->q_nope) && a->k_nope, "fl_mla_decode: null q/k pointer");
+  FL_CHECK_ARG(!per_token || ((q_bf16 || (a->q_rope && a->q_scale)) && a->k_rope && a->k_scale),
                "fl_mla_decode(per-token fp8): null rope/scale pointer");
+  FL_CHECK_ARG(!q_bf16 || (per_token && fl_mla_use_y() && a->s_q * a->h_q > 32 && ((uintptr_t)a->q_bf16 % 16) == 0),
+               "fl_mla_decode: q_bf16 (K4 inside the decode kernel) is served for the per-token format with more than 32 query rows "
+               "per request (role-specialised kernel), 16-byte aligned");
   FL_CHECK_ARG(a->block_table && a->cache_seqlens && a->tile_scheduler_metadata && a->num_splits && a->out && a->lse &&
                    a->o_accum && a->lse_accum,
                "fl_mla_decode: null metadata/output pointer");
@@ -930,6 +934,7 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   p.out = (uint16_t*)a->out; p.lse = a->lse; p.o_accum = a->o_accum; p.lse_accum = a->lse_accum;
   p.partial_bf16 = 0;
   p.merge_in_kernel = 0;
+  p.q_bf16 = (const uint16_t*)a->q_bf16;
   // The slot-pipelined mapping (mla_decode_fp8_x.hip): 128-row workgroups for rows > 64 (e.g. TP1, H=128); for 33..64 rows
   // two compute waves + two loader waves (measured H=64: 102.5 vs 114 us; FLUENT_MLA_X_SMALL=0 keeps this file's kernel).
   // At most 32 rows stay here: ONE slot-pipelined compute wave would carry all 40 MFMAs of a page on one SIMD (H=16:

@@ -532,7 +532,8 @@ __device__ __forceinline__ void qk_step1(float& l_run, float& lq_run, float& m_w
   }
 }
 
-template <int FMT>
+template <int FMT, bool QBF = false>   // QBF: the query arrives unquantised (bf16) and K4 runs in the QK waves' request prologue
+
 __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const Params p, const int32_t* __restrict__ g_block_table, const int32_t* __restrict__ g_seqlens,
     const int32_t* __restrict__ g_meta, int32_t* g_merge_ctr, const int32_t* __restrict__ g_num_splits,
@@ -623,7 +624,65 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       uint8_t* qr_lds = smem + kOffQr + w4 * 4096;
       float qs = 0.f;
       constexpr int kQRow = FMT == 1 ? kDN + kDR : kDN;   // bytes per query row (FMT 1: one fp8 [.,576] tensor)
-      if (row_ok) {
+      if constexpr (QBF) {
+        // K4 (quantize_ckv_per_token_head, flashmla_backend.py:198-206; arithmetic of mla_quant.hip) on this lane's half of its
+        // row: k-step s needs latent elements [64 s + 32 lh, + 32) as fp8 = 64 B of bf16; the row maximum spans both lane halves.
+        // The conversion (~1,000 VALU instructions) runs while the PV waves wait for the request's first page.
+        const uint16_t* qb = p.q_bf16 + (row_ok ? qrow : 0) * (kDN + kDR);   // (clamped: the loads are unconditional)
+        // pass 1: the row maximum — this lane's 256 elements streamed through 16 registers per k-step, then the other lane half's
+        float amax = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          uint4 raw[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(qb + 64 * s + 32 * lh + 8 * u);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t w4[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+              amax = fmaxf(amax, fmaxf(fabsf(__uint_as_float(w4[q4] << 16)), fabsf(__uint_as_float(w4[q4] & 0xffff0000u))));
+          }
+        }
+        {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+          amax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float qscale = fmaxf(amax, 1e-26f) / FL_FP8_MAX;
+        // pass 2: the same 64 B per k-step again (L2 hits), divided by the scale -> the k-step's 32 fp8 bytes; one k-step at a time
+        // (kept apart by scheduling barriers: with all eight in flight hipcc spilled 506 registers)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          uint4 raw[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(qb + 64 * s + 32 * lh + 8 * u);
+          uint2 w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t w4[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+            float v[8];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) { v[2 * q4] = __uint_as_float(w4[q4] << 16); v[2 * q4 + 1] = __uint_as_float(w4[q4] & 0xffff0000u); }
+            w[u] = fl_div8_to_fp8<false>(v, qscale);
+          }
+          qn[s] = row_ok ? v8i{(int)w[0].x, (int)w[0].y, (int)w[1].x, (int)w[1].y, (int)w[2].x, (int)w[2].y, (int)w[3].x, (int)w[3].y}
+                         : v8i{0, 0, 0, 0, 0, 0, 0, 0};
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const uint4 rr = *reinterpret_cast<const uint4*>(qb + kDN + lh * 8 + s * 16);
+          const uint32_t w4[4] = {rr.x, rr.y, rr.z, rr.w};
+          uint32_t o4[4];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+            o4[q4] = (uint32_t)fl_f32_to_bf16(__uint_as_float(w4[q4] << 16) / qscale) |
+                     ((uint32_t)fl_f32_to_bf16(__uint_as_float(w4[q4] & 0xffff0000u) / qscale) << 16);
+          *reinterpret_cast<uint4*>(qr_lds + s * 1024 + lane * 16) = row_ok ? make_uint4(o4[0], o4[1], o4[2], o4[3]) : make_uint4(0, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        qs = row_ok ? qscale * p.scale_log2e : 0.f;
+      } else if (row_ok) {
         const uint8_t* qp = g_q_nope + qrow * kQRow + lh * 32;
 #pragma unroll
         for (int s = 0; s < 8; ++s)
@@ -1035,6 +1094,10 @@ int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipSt
     mla_decode_y_kernel<1><<<grid, block, 0, stream>>>(
         p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, const_cast<int32_t*>(a->tile_scheduler_metadata), a->num_splits,
         (const uint8_t*)a->k_nope, (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
+  else if (p.q_bf16 != nullptr)
+    mla_decode_y_kernel<0, true><<<grid, block, 0, stream>>>(
+        p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, const_cast<int32_t*>(a->tile_scheduler_metadata), a->num_splits,
+        (const uint8_t*)a->k_nope, (const uint16_t*)a->k_rope, a->k_scale, nullptr, nullptr, nullptr);
   else
   mla_decode_y_kernel<0><<<grid, block, 0, stream>>>(
       p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, const_cast<int32_t*>(a->tile_scheduler_metadata), a->num_splits,

@@ -10,4 +10,5 @@ from fluent_mi355.mla import (  # noqa: F401
     quantize_ckv_per_token_head,
     quantize_q_and_cache_k,   # K5 + K4 in one launch: an extension over the reference module
     absorb_rope_quant,        # absorption bmm + RoPE + K5 + K4 in one launch: likewise an extension
+    flash_mla_ckv_fp8_per_token_bf16_q,   # K4 inside the decode kernel's prologue: likewise an extension
 )

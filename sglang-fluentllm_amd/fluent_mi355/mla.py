@@ -264,6 +264,33 @@ def flash_mla_ckv_fp8_per_token(q_nope: torch.Tensor, q_rope: torch.Tensor, k_ca
     return out, lse
 
 
+def flash_mla_ckv_fp8_per_token_bf16_q(q: torch.Tensor, k_cache_lora: torch.Tensor, k_cache_rope: torch.Tensor, k_scale: torch.Tensor,
+                                       block_table: torch.Tensor, cache_seqlens: torch.Tensor, head_dim_v: int,
+                                       tile_scheduler_metadata: torch.Tensor, num_splits: torch.Tensor,
+                                       softmax_scale: Optional[float] = None, causal: bool = False):
+    """`flash_mla_ckv_fp8_per_token(*quantize_ckv_per_token_head(q, 512), ...)` in ONE launch: the decode kernel quantises the query
+    (K4, flashmla_backend.py:198-206) in its request prologue — bit-identical output, one launch and a write + re-read of the quantised
+    query less.  q bf16 [bs, s_q, H, 576] (the absorbed query as forward_absorb_prepare builds it), more than 32 query rows per request.
+    An extension over the reference's module."""
+    for t, n in ((q, "q"), (k_cache_lora, "k_cache_lora"), (k_cache_rope, "k_cache_rope"), (k_scale, "k_scale")):
+        _cuda_contig(t, n)
+    _req(q.dim() == 4 and q.dtype == torch.bfloat16 and q.shape[-1] == 576 and head_dim_v == 512, "q must be bf16 [bs,s_q,H,576]")
+    _req(q.shape[1] * q.shape[2] > 32, "the fused-K4 decode serves more than 32 query rows per request (use the two-call form below that)")
+    _req(k_cache_rope.dtype == torch.bfloat16 and k_scale.dtype == torch.float32 and k_cache_lora.dtype in _ONE_BYTE, "bad cache dtypes")
+    _req(k_cache_lora.shape[1] == PAGE_SIZE, "page size must be 64")
+    if softmax_scale is None:
+        softmax_scale = 576 ** -0.5
+    a = FlMlaDecodeArgs()
+    a.kv_format = KV_FP8_PER_TOKEN
+    a.d_nope, a.d_rope = 512, 64
+    a.q_bf16 = q.data_ptr()
+    a.k_nope, a.k_rope, a.k_scale = k_cache_lora.data_ptr(), k_cache_rope.data_ptr(), k_scale.data_ptr()
+    a.num_pages = k_cache_lora.shape[0]
+    out, lse, _ws = _common(a, q, block_table, cache_seqlens, tile_scheduler_metadata, num_splits, softmax_scale, causal)
+    _decode(a, q.device)
+    return out, lse
+
+
 def flash_mla_with_kvcache(q: torch.Tensor, k_cache: torch.Tensor, block_table: torch.Tensor,
                            cache_seqlens: torch.Tensor, head_dim_v: int, tile_scheduler_metadata: torch.Tensor,
                            num_splits: torch.Tensor, softmax_scale: Optional[float] = None, causal: bool = False,

@@ -95,6 +95,41 @@ def test_fused_quant_q_and_cache_k_matches_the_two_separate_calls(fm):
         assert torch.equal(qr.view(torch.int16), rr.view(torch.int16))
 
 
+@pytest.mark.parametrize("bs,H,s_q,lens", [(5, 128, 1, [4096, 1, 63, 700, 129]), (3, 40, 1, [300, 64, 5000]), (4, 64, 4, [900, 130, 4, 2048]),
+                                           (128, 128, 1, None)])
+def test_decode_with_the_query_quantised_in_its_prologue_is_bit_identical(fm, bs, H, s_q, lens):
+    """flash_mla_ckv_fp8_per_token_bf16_q (K4 inside K1's request prologue) == quantize_ckv_per_token_head + flash_mla_ckv_fp8_per_token:
+    the same Q bytes reach the same kernel body, so outputs and LSEs are identical bit for bit — also with split requests (small
+    batches on 128 parts), padded head counts (H = 40) and the causal s_q = 4 verify step."""
+    g = torch.Generator().manual_seed(1000 + bs + H)
+    if lens is None:
+        lens = [2048 + int(torch.randint(0, 4096, (1,), generator=g)) for _ in range(bs)]
+    pages_per = [(l + 63) // 64 for l in lens]
+    total = sum(pages_per) + 1
+    perm = (torch.randperm(total - 1, generator=g) + 1).tolist()
+    bt = torch.zeros(bs, max(pages_per), dtype=torch.int32)
+    k = 0
+    for b, n in enumerate(pages_per):
+        bt[b, :n] = torch.tensor(perm[k:k + n], dtype=torch.int32)
+        k += n
+    key = (torch.randn(total * 64, 1, 576, generator=g) * torch.exp(torch.randn(total * 64, 1, 1, generator=g) * 0.5)).to(torch.bfloat16).to(dev())
+    k_lora = torch.zeros(total * 64, 1, 512, dtype=torch.uint8, device=dev())
+    k_scale = torch.zeros(total * 64, 1, 1, device=dev())
+    k_rope = torch.zeros(total * 64, 1, 64, dtype=torch.bfloat16, device=dev())
+    fm.quantize_and_cache_k(key, k_lora, k_scale, k_rope, torch.arange(total * 64, dtype=torch.int32, device=dev()), 512)
+    q = (torch.randn(bs, s_q, H, 576, generator=g) * torch.exp(torch.randn(bs, s_q, H, 1, generator=g))).to(torch.bfloat16).to(dev())
+    seq = torch.tensor(lens, dtype=torch.int32, device=dev())
+    meta, ns = fm.get_mla_metadata(seq, s_q * H, 1)
+    cache = (k_lora.view(total, 64, 1, 512), k_rope.view(total, 64, 1, 64), k_scale.view(total, 64, 1, 1))
+    qn, qs, qr = fm.quantize_ckv_per_token_head(q, 512)
+    o1, l1 = fm.flash_mla_ckv_fp8_per_token(qn, qr, cache[0], cache[1], qs, cache[2], bt.to(dev()), seq, 512, meta, ns, SCALE, True)
+    o2, l2 = fm.flash_mla_ckv_fp8_per_token_bf16_q(q, cache[0], cache[1], cache[2], bt.to(dev()), seq, 512, meta, ns, SCALE, True)
+    torch.cuda.synchronize()
+    assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
+    assert torch.equal(l1, l2)
+    assert int(meta[:, 5:].abs().sum()) == 0        # the in-kernel merge counters are back to zero
+
+
 # ---------------------------------------------------------------- K3: scheduler, bit-exact vs its Python statement
 @pytest.mark.parametrize("lens,rows", [([4096] * 128, 128), ([1] * 160, 16), ([0, 5, 200, 0, 9000], 128),
                                        ([16384], 64), ([63, 64, 65, 4095, 4097] * 7, 512)])
