@@ -267,7 +267,9 @@ int fl_ep_route(const int32_t* indices /*[num_pairs] global expert ids*/, int64_
  * type (int32 / f32 / bf16); 0 = dense ([rows, top_k] resp. [rows, hidden]). */
 int fl_ep_route_dedup(const int32_t* indices /*[tokens, top_k] global expert ids*/, int64_t num_tokens, int top_k,
                       int experts_per_rank, int world, int cap, int32_t* tok_slot, int32_t* send_eid, int32_t* pair_src,
-                      int64_t eid_row_stride, fl_stream_t stream);
+                      int64_t eid_row_stride,
+                      const float* weights /*optional [tokens, top_k] f32: placed beside the ids (send_w[row, j], 0 = padding)*/,
+                      float* send_w, int64_t w_row_stride, fl_stream_t stream);
 int fl_ep_gather_f32(const float* vals, int64_t n, const int32_t* src /*[out_n]*/, float* out /*out[j] = vals[src[j]], 0 where src[j] is not in [0, n)*/,
                      int64_t out_n, int per_row /*entries per output row*/, int64_t out_row_stride, fl_stream_t stream);
 int fl_ep_gather_rows_div(const void* src, int64_t src_rows, const int32_t* idx, int64_t n, int div /*dst[i] = src[idx[i] / div]*/,

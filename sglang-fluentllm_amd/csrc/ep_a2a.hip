@@ -47,7 +47,11 @@ __global__ __launch_bounds__(256) void ep_route_kernel(const int32_t* __restrict
 __global__ __launch_bounds__(256) void ep_route_dedup_kernel(const int32_t* __restrict__ indices, int T, int top_k,
                                                              int experts_per_rank, int world, int cap,
                                                              int32_t* __restrict__ tok_slot, int32_t* __restrict__ send_eid,
-                                                             int32_t* __restrict__ pair_src, long long eid_stride) {
+                                                             int32_t* __restrict__ pair_src, long long eid_stride,
+                                                             const float* __restrict__ weights, float* __restrict__ send_w,
+                                                             long long w_stride) {
+  // (weights != nullptr: the routing weight of every pair is placed beside its expert id — send_w[row, j] = weights[t, k], 0 for
+  //  padding — in the same pass: the dispatch message's tail is complete without a gather launch)
   // (eid_stride: ints between the id rows — top_k for a separate [rows, top_k] tensor, the message row for ids that travel in the
   //  TAIL of their slab row: one all-to-all instead of two)
   extern __shared__ unsigned long long s_mask[];   // [T] peers of every token (world <= 64)
@@ -55,6 +59,7 @@ __global__ __launch_bounds__(256) void ep_route_dedup_kernel(const int32_t* __re
   for (long long i = threadIdx.x; i < (long long)world * cap * top_k; i += 256) {
     send_eid[(i / top_k) * eid_stride + i % top_k] = -1;
     pair_src[i] = -1;
+    if (weights != nullptr) send_w[(i / top_k) * w_stride + i % top_k] = 0.f;
   }
   for (int t = threadIdx.x; t < T; t += 256) {
     unsigned long long m = 0;
@@ -92,6 +97,7 @@ __global__ __launch_bounds__(256) void ep_route_dedup_kernel(const int32_t* __re
           }
           send_eid[(long long)row * eid_stride + j] = e - d * experts_per_rank;
           pair_src[(long long)row * top_k + j] = t * top_k + k;
+          if (weights != nullptr) send_w[(long long)row * w_stride + j] = weights[t * top_k + k];
         }
       }
     }
@@ -251,14 +257,16 @@ extern "C" int fl_ep_route(const int32_t* indices, int64_t num_pairs, int expert
 }
 
 extern "C" int fl_ep_route_dedup(const int32_t* indices, int64_t num_tokens, int top_k, int experts_per_rank, int world, int cap,
-                                 int32_t* tok_slot, int32_t* send_eid, int32_t* pair_src, int64_t eid_row_stride, fl_stream_t stream) {
+                                 int32_t* tok_slot, int32_t* send_eid, int32_t* pair_src, int64_t eid_row_stride, const float* weights,
+                                 float* send_w, int64_t w_row_stride, fl_stream_t stream) {
+  FL_CHECK_ARG(weights == nullptr || (send_w != nullptr && (w_row_stride == 0 || w_row_stride >= top_k)), "fl_ep_route_dedup: bad weight outputs");
   FL_CHECK_ARG(eid_row_stride == 0 || eid_row_stride >= top_k, "fl_ep_route_dedup: eid_row_stride=%lld < top_k", (long long)eid_row_stride);
   FL_CHECK_ARG(send_eid && pair_src && (num_tokens == 0 || (indices && tok_slot)), "fl_ep_route_dedup: null pointer");
   FL_CHECK_ARG(world >= 1 && world <= 64 && cap >= 1 && experts_per_rank >= 1 && top_k >= 1 && num_tokens >= 0 &&
                    num_tokens <= 8192, "fl_ep_route_dedup: bad sizes (tokens per rank <= 8192, world <= 64)");
   ep_route_dedup_kernel<<<1, 256, (size_t)(num_tokens > 0 ? num_tokens : 1) * 8, (hipStream_t)stream>>>(
       indices, (int)num_tokens, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_src,
-      eid_row_stride > 0 ? eid_row_stride : top_k);
+      eid_row_stride > 0 ? eid_row_stride : top_k, weights, send_w, w_row_stride > 0 ? w_row_stride : top_k);
   FL_CHECK_LAUNCH("fl_ep_route_dedup");
   return FL_OK;
 }

@@ -35,7 +35,7 @@ class HipRowOps:
         self._ct, self._check, self._lib, self._stream = ctypes, check, lib, stream_ptr
         vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
         lib.fl_ep_route.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp]
-        lib.fl_ep_route_dedup.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp, vp, i64, vp]
+        lib.fl_ep_route_dedup.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp, i64, vp]
         lib.fl_ep_sort.argtypes = [vp, i64, i32, vp, vp, vp, i32, i64, vp]
         lib.fl_ep_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64, vp]
         lib.fl_ep_gather_rows_div.argtypes = [vp, i64, vp, i64, i32, i32, vp, i64, vp, i64, vp]
@@ -63,11 +63,16 @@ class HipRowOps:
             raise RuntimeError(f"{name} must be a [rows, cols] tensor or view with a contiguous last dimension")
         return t.stride(0) if t.shape[0] > 1 else t.shape[1]
 
-    def route_dedup(self, indices, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_src):
-        """send_eid: int32 [world*cap, top_k] (a view into the message tail is fine)"""
+    def route_dedup(self, indices, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_src, weights=None, send_w=None):
+        """send_eid: int32 [world*cap, top_k] (a view into the message tail is fine); weights f32 [tokens*top_k] + send_w f32
+        [world*cap, top_k] (view ok): the routing weights placed beside the ids in the same launch"""
         self._check(self._lib.fl_ep_route_dedup(indices.data_ptr(), indices.numel() // top_k, top_k, experts_per_rank, world, cap,
                                                 tok_slot.data_ptr(), send_eid.data_ptr(), pair_src.data_ptr(),
-                                                self._rows2d(send_eid, "send_eid"), self._stream(send_eid.device)), "fl_ep_route_dedup")
+                                                self._rows2d(send_eid, "send_eid"),
+                                                None if weights is None else weights.data_ptr(),
+                                                None if send_w is None else send_w.data_ptr(),
+                                                0 if send_w is None else self._rows2d(send_w, "send_w"),
+                                                self._stream(send_eid.device)), "fl_ep_route_dedup")
 
     def sort(self, recv_eid, num_local_experts, order, exclusive_sum, inverse=None):
         """recv_eid: int32 [rows, top_k] (view ok); order / inverse index the flattened (row, j) pairs"""
@@ -165,10 +170,12 @@ class AllToAll:
         tok_slot = torch.empty(t * W, dtype=torch.int32, device=dev)
         pair_src = torch.empty(S * K, dtype=torch.int32, device=dev)
         msg, send_rows, send_eid, send_w = self._message(dp_x.dtype, dev)
-        self.row_ops.route_dedup(idx, K, self.experts_per_rank, W, self.cap, tok_slot, send_eid, pair_src)
+        if weights is not None:   # ids and weights into the row tails in ONE launch
+            self.row_ops.route_dedup(idx, K, self.experts_per_rank, W, self.cap, tok_slot, send_eid, pair_src,
+                                     weights.to(torch.float32).reshape(-1).contiguous(), send_w)
+        else:
+            self.row_ops.route_dedup(idx, K, self.experts_per_rank, W, self.cap, tok_slot, send_eid, pair_src)
         self.row_ops.send(dp_x.contiguous(), tok_slot, W, send_rows)              # empty rows: never read (all their ids are -1)
-        if weights is not None:
-            self.row_ops.gather_f32(weights.to(torch.float32).reshape(-1).contiguous(), pair_src, send_w)
         recv = self._a2a(msg)                                                     # ONE message: rows + ids (+ weights)
         h2 = self.hidden // 2
         recv_rows, recv_eid = recv[:, :self.hidden], recv.view(torch.int32)[:, h2:h2 + K]

@@ -5,9 +5,11 @@ import torch
 
 
 class TorchRowOps:
-    def route_dedup(self, indices, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_src):
+    def route_dedup(self, indices, top_k, experts_per_rank, world, cap, tok_slot, send_eid, pair_src, weights=None, send_w=None):
         send_eid.fill_(-1)
         pair_src.fill_(-1)
+        if weights is not None:
+            send_w.fill_(0)
         ids = indices.view(-1, top_k).tolist()
         T = len(ids)
         ts = [[-1] * world for _ in range(T)]
@@ -27,6 +29,8 @@ class TorchRowOps:
                     if row >= 0:
                         send_eid[row, seen[d]] = e - d * experts_per_rank      # [rows, top_k] (possibly a view into the message tail)
                         pair_src[row * top_k + seen[d]] = t * top_k + k
+                        if weights is not None:
+                            send_w[row, seen[d]] = weights[t * top_k + k]
                     seen[d] += 1
         if T:
             tok_slot.copy_(torch.tensor(ts, dtype=torch.int32).view(-1))

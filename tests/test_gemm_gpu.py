@@ -413,6 +413,11 @@ def test_ep_dedup_row_kernels_match_the_torch_row_ops_world4_routing(layout):
         ops.send(x.to(dev), ts, W, rows)
         vals = torch.rand(T * K, generator=torch.Generator().manual_seed(5)).to(dev)
         ops.gather_f32(vals, pp, placed)
+        # the same weights placed by the routing launch itself (dispatch(..., weights=): no gather launch)
+        placed2 = torch.full((S, K), 7.0, dtype=torch.float32, device=dev)
+        ops.route_dedup(idx.to(dev).reshape(-1), K, EPR, W, cap, torch.empty_like(ts), torch.empty(S, K, dtype=torch.int32, device=dev),
+                        torch.empty_like(pp), vals, placed2)
+        assert torch.equal(placed2.cpu(), placed.cpu().contiguous())
         order = torch.empty(S * K, dtype=torch.int32, device=dev)
         ex = torch.empty(EPR + 1, dtype=torch.int32, device=dev)
         inv = torch.full((S * K,), -1, dtype=torch.int32, device=dev)
