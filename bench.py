@@ -26,7 +26,7 @@ import torch  # noqa: E402
 LAYERS = 61
 BS, SEQ, H, S_Q = 128, 4096, 128, 1
 SCALE = 192 ** -0.5
-FUSED_QUANT = os.environ.get("FLUENT_BENCH_FUSED_QUANT", "1") != "0"
+FUSED_QUANT = os.environ.get("FLUENT_BENCH_FUSED_QUANT", "0") == "1"   # headline = the reference's unmodified call sequence (K5, K4, K1)
 K4_IN_K1 = os.environ.get("FLUENT_BENCH_K4_IN_K1", "0") == "1"   # experiment switch, see layer_call
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling ~6290 GB/s
 
@@ -64,14 +64,15 @@ def build_workload(dev, layers, bs, seq, h, seed):
     return dict(caches=caches, block_table=block_table, seqlens=seqlens, q=q, k_new=k_new, out_loc=out_loc, pages=pages)
 
 
-def layer_call(fm, wl, l, meta, ns):
+def layer_call(fm, wl, l, meta, ns, fused=None):
+    fused = FUSED_QUANT if fused is None else fused
     k_lora, k_scale, k_rope = wl["caches"][l]
     pages = wl["pages"]
     if K4_IN_K1:      # K5 alone, K4 inside K1's request prologue (flash_mla_fp8.flash_mla_ckv_fp8_per_token_bf16_q)
         fm.quantize_and_cache_k(wl["k_new"], k_lora, k_scale, k_rope, wl["out_loc"], 512)
         return fm.flash_mla_ckv_fp8_per_token_bf16_q(wl["q"], k_lora.view(pages, 64, 1, 512), k_rope.view(pages, 64, 1, 64),
                                                      k_scale.view(pages, 64, 1, 1), wl["block_table"], wl["seqlens"], 512, meta, ns, SCALE, True)
-    if FUSED_QUANT:   # K5 + K4 in one launch (flash_mla_fp8.quantize_q_and_cache_k): 2 launches per layer instead of 3
+    if fused:   # K5 + K4 in one launch (flash_mla_fp8.quantize_q_and_cache_k): 2 launches per layer instead of 3
         qn, qs, qr = fm.quantize_q_and_cache_k(wl["q"], wl["k_new"], k_lora, k_scale, k_rope, wl["out_loc"], 512)
     else:             # the call sequence of the unmodified FlashMLABackend.forward_decode (flashmla_backend.py:188-206)
         fm.quantize_and_cache_k(wl["k_new"], k_lora, k_scale, k_rope, wl["out_loc"], 512)
@@ -525,6 +526,51 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     tokens_per_s = world * BS / (ms_per_step * 1e-3) * (layers / LAYERS)   # (a step of fewer layers is scaled to the 61-layer step)
 
+    # ---- sub-records of the same step (rank 0, N = 1): (a) the optional fused quant launch (flash_mla_fp8.quantize_q_and_cache_k: an
+    #      extension entry point an integrator may call instead of K5 + K4 — NOT what the unmodified FlashMLABackend calls, hence
+    #      not the headline), (b) the quant launches alone, so that K1's share of the timed step can be read off ----
+    step_variants = None
+    if rank == 0 and world == 1 and graph is not None:
+        def timed_graph(body, reps):
+            s3 = torch.cuda.Stream()
+            s3.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s3):
+                body()
+            torch.cuda.current_stream().wait_stream(s3)
+            gx = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gx):
+                body()
+            gx.replay()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(reps):
+                gx.replay()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0_) / reps * 1e3
+
+        def fused_step():
+            m_step, ns_step = fm.get_mla_metadata(wl["seqlens"], S_Q * H, 1)
+            for l in range(layers):
+                layer_call(fm, wl, l, m_step, ns_step, fused=not FUSED_QUANT)
+
+        def quant_only_step():
+            fm.get_mla_metadata(wl["seqlens"], S_Q * H, 1)
+            for l in range(layers):
+                k_lora, k_scale, k_rope = wl["caches"][l]
+                if FUSED_QUANT:
+                    fm.quantize_q_and_cache_k(wl["q"], wl["k_new"], k_lora, k_scale, k_rope, wl["out_loc"], 512)
+                else:
+                    fm.quantize_and_cache_k(wl["k_new"], k_lora, k_scale, k_rope, wl["out_loc"], 512)
+                    fm.quantize_ckv_per_token_head(wl["q"], 512)
+
+        ms_other = timed_graph(fused_step, max(3, a.steps // 2))
+        ms_quant = timed_graph(quant_only_step, max(3, a.steps // 2))
+        other = "K5, K4 separate (reference call sequence)" if FUSED_QUANT else "K5 + K4 fused (flash_mla_fp8.quantize_q_and_cache_k, extension)"
+        step_variants = {"other_quant_form": {"quant_launch": other, "ms_per_step": round(ms_other, 4),
+                                              "tokens_per_s": round(BS / (ms_other * 1e-3) * (layers / LAYERS), 1)},
+                         "quant_launches_only_ms_per_step": round(ms_quant, 4),
+                         "k1_us_per_launch_inside_the_timed_step": round((ms_per_step - ms_quant) * 1e3 / layers, 2)}
+
     # ---- roofline of the dominant kernel: K1 alone, HIP events on the launch stream (torch's current stream) ----
     roof = None
     if rank == 0:
@@ -594,6 +640,8 @@ def main():
         wl = None
         torch.cuda.empty_cache()
         variants = {"cfg2_ragged": k1_ragged_variant(dev)}
+        if step_variants is not None:
+            variants["step"] = step_variants
         torch.cuda.empty_cache()
         gemm = gemm_roofline(dev)
         try:

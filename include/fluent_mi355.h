@@ -142,6 +142,9 @@ typedef struct FlMlaDecodeArgs {
   const void* q_bf16;       /* optional (FL_KV_FP8_PER_TOKEN, s_q*h_q > 32): the UNQUANTISED query bf16 [bs,s_q,h_q,576]; the decode
                              * kernel then does quantize_ckv_per_token_head (K4, flashmla_backend.py:198-206) in its own prologue — same
                              * bytes, same result, one launch and a write + re-read of Q less; q_nope / q_rope / q_scale are ignored */
+  int64_t block_table_cols; /* columns of a block_table row that may be read (block_table.shape[1]); 0 = block_table_stride.  The row
+                             * stride is NOT the row width for an expanded (stride 0) or sliced table: the kernels clamp their
+                             * unconditional page-id loads against THIS */
 } FlMlaDecodeArgs;
 
 int fl_mla_decode(const FlMlaDecodeArgs* args, fl_stream_t stream);

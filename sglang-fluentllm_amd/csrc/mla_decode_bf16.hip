@@ -298,6 +298,7 @@ int fl_mla_decode_bf16_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   p.scale_log2e = a->softmax_scale * kLog2e;
   p.descale_q = nullptr; p.descale_k = nullptr;
   p.num_pages = a->num_pages; p.bt_stride = a->block_table_stride;
+  p.bt_cols = a->block_table_cols > 0 ? a->block_table_cols : (a->block_table_stride > 0 ? a->block_table_stride : 1);
   p.out = (uint16_t*)a->out; p.lse = a->lse; p.o_accum = a->o_accum; p.lse_accum = a->lse_accum;
   p.partial_bf16 = 0;
   p.merge_in_kernel = 0;

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const int t = base + lane;                                                                                         \
     /* UNCONDITIONAL load on an index clamped into the request's table row: the load does not wait for the sequence  */ \
     /* length (n) — at a request's start both go out together, one memory round trip less in the prologue chain       */ \
-    const long long col = tile_b + t < p.bt_stride ? tile_b + t : p.bt_stride - 1;                                     \
+    const long long col = tile_b + t < p.bt_cols ? tile_b + t : p.bt_cols - 1;                                         \
     const int pg = g_block_table[(long long)req * p.bt_stride + (col < 0 ? 0 : col)];                                  \
     pg_vec = (t >= n || pg < 0 || pg >= p.num_pages) ? 0 : pg;                                                         \
   };                                                                                                                   \

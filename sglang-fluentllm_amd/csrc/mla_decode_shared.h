@@ -26,6 +26,7 @@ struct Params {
   const float* descale_k;
   long long num_pages;
   long long bt_stride;
+  long long bt_cols;   // readable columns of a block-table row (>= 1)
   uint16_t* out;
   float* lse;
   float* o_accum;

@@ -25,7 +25,7 @@ class FlMlaDecodeArgs(ctypes.Structure):
         ("block_table", _i32p), ("block_table_stride", ctypes.c_int64),
         ("cache_seqlens", _i32p), ("tile_scheduler_metadata", _i32p), ("num_splits", _i32p),
         ("out", _c_void_p), ("lse", _f32p), ("o_accum", _f32p), ("lse_accum", _f32p),
-        ("q_bf16", _c_void_p),
+        ("q_bf16", _c_void_p), ("block_table_cols", ctypes.c_int64),
     ]
 
 

@@ -220,6 +220,7 @@ def _common(args, q_like, block_table, cache_seqlens, tile_scheduler_metadata, n
     args.softmax_scale = float(softmax_scale)
     args.block_table = block_table.data_ptr()
     args.block_table_stride = block_table.stride(0)
+    args.block_table_cols = block_table.shape[1]
     args.cache_seqlens = cache_seqlens.data_ptr()
     args.tile_scheduler_metadata = tile_scheduler_metadata.data_ptr()
     args.num_splits = num_splits.data_ptr()

@@ -95,6 +95,45 @@ def test_fused_quant_q_and_cache_k_matches_the_two_separate_calls(fm):
         assert torch.equal(qr.view(torch.int16), rr.view(torch.int16))
 
 
+@pytest.mark.parametrize("H", [128, 16])
+def test_decode_with_an_expanded_or_sliced_block_table(fm, H):
+    """The row stride of block_table is not its row width: (a) one table row shared by every request through
+    expand() (stride(0) == 0) and (b) a column slice of a wider table (stride(0) > shape[1]) give the bytes of the same launch
+    on a contiguous copy of the table — for the > 32-row kernel (unconditional, clamped page-id loads) and the <= 32-row one."""
+    g = torch.Generator().manual_seed(4242 + H)
+    bs, L = 3, 700
+    npg = (L + 63) // 64
+    total = 2 * npg + 1
+    key = torch.randn(total * 64, 1, 576, generator=g).to(torch.bfloat16).to(dev())
+    k_lora = torch.zeros(total * 64, 1, 512, dtype=torch.uint8, device=dev())
+    k_scale = torch.zeros(total * 64, 1, 1, device=dev())
+    k_rope = torch.zeros(total * 64, 1, 64, dtype=torch.bfloat16, device=dev())
+    fm.quantize_and_cache_k(key, k_lora, k_scale, k_rope, torch.arange(total * 64, dtype=torch.int32, device=dev()), 512)
+    cache = (k_lora.view(total, 64, 1, 512), k_rope.view(total, 64, 1, 64), k_scale.view(total, 64, 1, 1))
+    q = torch.randn(bs, 1, H, 576, generator=g).to(torch.bfloat16).to(dev())
+    qn, qs, qr = fm.quantize_ckv_per_token_head(q, 512)
+    seq = torch.full((bs,), L, dtype=torch.int32, device=dev())
+    meta, ns = fm.get_mla_metadata(seq, H, 1)
+    row = (torch.randperm(total - 1, generator=g)[:npg] + 1).to(torch.int32).to(dev())
+
+    def run(bt):
+        o, lse = fm.flash_mla_ckv_fp8_per_token(qn, qr, cache[0], cache[1], qs, cache[2], bt, seq, 512, meta, ns, SCALE, True)
+        torch.cuda.synchronize()
+        return o, lse
+
+    shared = row.view(1, npg).expand(bs, npg)
+    assert shared.stride(0) == 0
+    o_ref, l_ref = run(shared.contiguous())
+    o, lse = run(shared)
+    assert torch.equal(o.view(torch.int16), o_ref.view(torch.int16)) and torch.equal(lse, l_ref)
+    wide = torch.full((bs, npg + 37), 10 ** 6, dtype=torch.int32, device=dev())    # (page ids beyond the pool in the columns that must not be read)
+    wide[:, :npg] = row
+    sliced = wide[:, :npg]
+    assert sliced.stride(0) == npg + 37
+    o, lse = run(sliced)
+    assert torch.equal(o.view(torch.int16), o_ref.view(torch.int16)) and torch.equal(lse, l_ref)
+
+
 @pytest.mark.parametrize("bs,H,s_q,lens", [(5, 128, 1, [4096, 1, 63, 700, 129]), (3, 40, 1, [300, 64, 5000]), (4, 64, 4, [900, 130, 4, 2048]),
                                            (128, 128, 1, None)])
 def test_decode_with_the_query_quantised_in_its_prologue_is_bit_identical(fm, bs, H, s_q, lens):
