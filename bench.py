@@ -618,19 +618,15 @@ def main():
         # HBM bytes per launch: NOT measured in this run — read from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 +
         # WRITE_SIZE, MI355X_MICROARCH.md) of the kernel this build dispatches at this workload; the source file is named
         traffic, traffic_src = None, None
-        y_on = os.environ.get("FLUENT_MLA_Y") != "0"
         try:
-            traffic_src = "profiles/r03_pmc_traffic.json" if y_on else "profiles/r01_pmc_traffic.json"
+            traffic_src = "profiles/r03_pmc_traffic.json"
             with open(os.path.join(ROOT, traffic_src)) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch"])
         except Exception:
             traffic_src = None
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": ("mla_decode_y_kernel" if (y_on and H * S_Q > 32) else
-                           "mla_decode_x_kernel" if (H * S_Q > 64 and os.environ.get("FLUENT_MLA_X") != "0")
-                           else "mla_decode_fp8_kernel") + (" (no merge kernel: split requests are merged inside the decode kernel; none is split at this shape)"
-                                                            if (y_on and H * S_Q > 32) else " (+ mla_combine_kernel)"),
+                "kernel": "mla_decode_y_kernel (no merge kernel: split requests are merged inside the decode kernel; none is split at this shape)",
                 "us_per_launch": round(per_launch_s * 1e6, 2),
                 "algorithmic_bytes_per_launch": alg}
     cpu = None
@@ -642,6 +638,17 @@ def main():
         variants = {"cfg2_ragged": k1_ragged_variant(dev)}
         if step_variants is not None:
             variants["step"] = step_variants
+        if os.environ.get("FLUENT_BENCH_CFG4_WORLD1", "1") != "0":
+            # BASELINE config 4's decoder layer (data-connected: tools/cfg4_layer.py) at world 1 — every stage of the TP8/EP8 layer on ONE
+            # GPU (all 128 heads, all 256 experts; collectives degenerate to their local kernels): ms per layer of the captured step + the
+            # eager per-stage split.  An add-on: never at the expense of the headline record.
+            try:
+                torch.cuda.empty_cache()
+                rec = measure_cfg4(a, dev, 1, 0, None, 2, 5, 2, stages=True)
+                variants["cfg4_world1"] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "ms_per_layer", "stage_ms", "config")}
+            except Exception as ex_:
+                variants["cfg4_world1"] = {"error": f"{type(ex_).__name__}: {ex_}"[:300]}
+            torch.cuda.empty_cache()
         torch.cuda.empty_cache()
         gemm = gemm_roofline(dev)
         try:
@@ -708,7 +715,7 @@ def _headline(tokens_per_s, world, a, ms_per_step, layers, graph_ok, roof, gemm,
             "roofline": roof, "gemm": gemm, "variants": variants, "cpu_baseline": cpu}
 
 
-def measure_cfg4(a, dev, world, rank, dist, layers, steps, warmup):
+def measure_cfg4(a, dev, world, rank, dist, layers, steps, warmup, stages=False):
     """-> the config-4 record (all ranks compute it; rank 0 prints / embeds it)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import cfg4_layer
@@ -750,15 +757,18 @@ def measure_cfg4(a, dev, world, rank, dist, layers, steps, warmup):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / steps * 1e3
+    stage_ms = info["_stage_times"]() if stages else None
     return {
+            "stage_ms": stage_ms,
             "metric": "decode tokens/s, DeepSeek-V3 decoder layers at BASELINE config 4 (attention-TP + EP MoE, bs=256 seq=8k), scaled to 61 layers",
             "value": round(info["bs"] / (ms_per_step * 1e-3) * (layers / LAYERS), 1), "unit": "tokens/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4), "ms_per_layer": round(ms_per_step / layers, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "fp8_e4m3 x fp8 -> f32 acc (attention, GEMMs); bf16 activations on the wire", "data": "synthetic",
-            "config": {"workload": f"DeepSeek-V3 decoder layer x{layers}: TP{world} MLA decode (H={info['heads_per_rank']}/rank, bs=256 "
+            "config": {"workload": f"DeepSeek-V3 decoder layer x{layers}, data-connected (qkv_a -> C7 -> q_b -> absorb+RoPE+K5+K4 -> K1 -> bmm_v -> o_proj -> "
+                                   f"C6 -> router -> EP -> experts || shared expert): TP{world} MLA decode (H={info['heads_per_rank']}/rank, bs=256 "
                                    f"seq=8192) + EP{world} MoE ({info['experts_per_rank']} experts/rank, top-8), all-gather + "
-                                   "reduce-scatter + EP dispatch/combine over RCCL inside the step",
+                                   "reduce-scatter + EP dispatch/combine inside the step",
                        "layers_per_step": layers, "parallelism": f"tp{world}/ep{world}", "hipgraph": graph is not None,
                        "hipgraph_refused": why, **{k: v for k, v in info.items() if not k.startswith("_")}},
             "roofline": None, "cpu_baseline": None}

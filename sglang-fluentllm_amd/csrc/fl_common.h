@@ -8,9 +8,6 @@
 #include "../../include/fluent_mi355.h"
 
 void fl_set_error(const char* fmt, ...);
-int fl_mla_x_rows_per_wg();   // 128, or 64 with FLUENT_MLA_X_ROWS=64 (see fl_common.hip)
-bool fl_mla_use_y();   // role-specialised 64-row MLA decode workgroups for s_q*H > 32, per-token FP8 (FLUENT_MLA_Y=0 disables)
-bool fl_mla_use_x();   // 128-row MLA decode workgroups for s_q*H > 64 + matching part count (FLUENT_MLA_X=0 disables)
 
 #define FL_CHECK_ARG(cond, ...)            \
   do {                                     \

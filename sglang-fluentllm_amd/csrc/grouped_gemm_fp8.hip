@@ -347,14 +347,12 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
   if (a->mode == kDense) avg = a->M;
   int mt = avg <= 32 ? 1 : (avg <= 64 ? 2 : 4);
   if (a->mode == kContiguous) mt = 4;   // groups are 128-row aligned by contract (deep_ep_executor.py:282,290)
-  // many rows per group (prefill regime): 256 x 256 tiles, one 8-wave workgroup per CU (grouped_gemm_fp8_big.hip)
-  // FLUENT_GEMM_BIG: 0 = never, 1 = round 1/2's lock-step kernel (grouped_gemm_fp8_big.hip), 2 = round 3's half-k ring with
-  // two wave groups in anti-phase (grouped_gemm_fp8_big2.hip; default)
-  static const int big_kind = [] {
+  // many rows per group (prefill regime): 256 x 256 tiles, one 8-wave workgroup per CU (grouped_gemm_fp8_big2.hip).
+  // FLUENT_GEMM_BIG=0 keeps the 128-row tiles for every shape (A/B runs); unset or empty: on.
+  static const bool big_on = [] {
     const char* e = getenv("FLUENT_GEMM_BIG");
-    return e != nullptr ? atoi(e) : FL_GEMM_BIG_DEFAULT;
+    return !(e != nullptr && e[0] == '0');
   }();
-  const bool big_on = big_kind != 0;
   // (contiguous groups are only 128-row aligned; the big tile addresses a weight panel with 32-bit offsets)
   static const long long big_min = [] {
     const char* e = getenv("FLUENT_GEMM_BIG_MIN_ROWS");
@@ -381,8 +379,7 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
   //  workgroup per tile by construction)
   if (!few_tiles && big_on && avg >= big_min && a->K >= 2 * BK && a->mode != kContiguous &&
       (long long)a->N * a->K < (1ll << 32) && g_num_cus_limit.load() == 0)
-    return big_kind == 1 ? fl_gemm_launch_big(p, a->A, a->As, a->W, a->Ws, a->group_meta, (hipStream_t)stream)
-                         : fl_gemm_launch_big2(p, a->A, a->As, a->W, a->Ws, a->group_meta, (hipStream_t)stream);
+    return fl_gemm_launch_big2(p, a->A, a->As, a->W, a->Ws, a->group_meta, (hipStream_t)stream);
   const int bm = 32 * mt;
   long long m_tiles;
   if (a->mode == kOffset) m_tiles = (a->M + bm - 1) / bm + a->num_groups;

@@ -229,7 +229,10 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
 #pragma unroll
   for (int j = 0; j < 4; ++j) { cmant[j] = 1.f; e8[j] = kUnit; ratio[j] = 1.f; }
 
-  const float* wsrow = gWs + ((long long)e * ((p.N + BN - 1) / BN) + (n0 + 64 * wn) / BN) * KB;
+  // (weight rows beyond N are clamped and their results discarded: their scale row is clamped too — no read past the tensor)
+  const int nb_last = (p.N + BN - 1) / BN - 1;
+  const int nb_w = (n0 + 64 * wn) / BN;
+  const float* wsrow = gWs + ((long long)e * (nb_last + 1) + (nb_w < nb_last ? nb_w : nb_last)) * KB;
   v8i wa[2], tb[4];
 
   // ---- segment L: operand reads, (first half of a k block:) scales + rescale of token blocks 2, 3.  No LDS-DMA here: the

@@ -109,11 +109,6 @@ __device__ __forceinline__ bool locate_tile(const GemmParams& p, const int32_t* 
 
 }  // namespace fl_gemm
 
-#ifndef FL_GEMM_BIG_DEFAULT
-#define FL_GEMM_BIG_DEFAULT 2
-#endif
-// 256 x 256 tile kernels: many rows per group (grouped_gemm_fp8_big.hip: rounds 1-2; grouped_gemm_fp8_big2.hip: round 3)
+// 256 x 256 tile kernel: many rows per group (grouped_gemm_fp8_big2.hip, round 3)
 int fl_gemm_launch_big2(const fl_gemm::GemmParams& p, const void* A, const float* As, const void* W, const float* Ws,
                         const int32_t* group_meta, hipStream_t stream);
-int fl_gemm_launch_big(const fl_gemm::GemmParams& p, const void* A, const float* As, const void* W, const float* Ws,
-                       const int32_t* group_meta, hipStream_t stream);

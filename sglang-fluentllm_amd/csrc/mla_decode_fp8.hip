@@ -888,7 +888,6 @@ int fl_mla_launch_combine(const Params& p, const int32_t* num_splits, hipStream_
   return FL_OK;
 }
 
-int fl_mla_decode_fp8_x_impl(const FlMlaDecodeArgs* a, const Params& p, hipStream_t stream);   // mla_decode_fp8_x.hip
 int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p, hipStream_t stream);   // mla_decode_fp8_y.hip
 
 // bytes of the split-partials workspaces fl_mla_decode needs for a launch of this shape — the SAME dispatch rule as below
@@ -897,13 +896,8 @@ extern "C" int fl_mla_workspace_bytes(int kv_format, int bs, int s_q, int h_q, i
                                       int64_t* lse_accum_bytes) {
   FL_CHECK_ARG(o_accum_bytes && lse_accum_bytes && bs >= 0 && s_q >= 1 && h_q >= 1 && num_parts >= 1, "fl_mla_workspace_bytes: bad arguments");
   const long long rows = (long long)s_q * h_q;
-  static const bool x_small = [] {
-    const char* e = getenv("FLUENT_MLA_X_SMALL");
-    return !(e != nullptr && e[0] == '0');
-  }();
-  bool bf16_partials = false;
-  if (kv_format != FL_KV_BF16_576 && fl_mla_use_y() && rows > 32) bf16_partials = true;
-  else if (kv_format != FL_KV_BF16_576 && fl_mla_use_x() && (rows > 64 || (x_small && rows > 32))) bf16_partials = true;
+  // more than 32 query rows per request (fp8 formats): the role-specialised kernel, whose split partials are bf16 rows
+  const bool bf16_partials = kv_format != FL_KV_BF16_576 && rows > 32;
   *o_accum_bytes = (long long)(bs + num_parts) * rows * 512 * (bf16_partials ? 2 : 4);
   *lse_accum_bytes = (long long)(bs + num_parts) * rows * 2 * 4;
   return FL_OK;
@@ -917,7 +911,7 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   FL_CHECK_ARG((q_bf16 || a->q_nope) && a->k_nope, "fl_mla_decode: null q/k pointer");
   FL_CHECK_ARG(!per_token || ((q_bf16 || (a->q_rope && a->q_scale)) && a->k_rope && a->k_scale),
                "fl_mla_decode(per-token fp8): null rope/scale pointer");
-  FL_CHECK_ARG(!q_bf16 || (per_token && fl_mla_use_y() && a->s_q * a->h_q > 32 && ((uintptr_t)a->q_bf16 % 16) == 0),
+  FL_CHECK_ARG(!q_bf16 || (per_token && a->s_q * a->h_q > 32 && ((uintptr_t)a->q_bf16 % 16) == 0),
                "fl_mla_decode: q_bf16 (K4 inside the decode kernel) is served for the per-token format with more than 32 query rows "
                "per request (role-specialised kernel), 16-byte aligned");
   FL_CHECK_ARG(a->block_table && a->cache_seqlens && a->tile_scheduler_metadata && a->num_splits && a->out && a->lse &&
@@ -936,35 +930,19 @@ int fl_mla_decode_fp8_impl(const FlMlaDecodeArgs* a, hipStream_t stream) {
   p.partial_bf16 = 0;
   p.merge_in_kernel = 0;
   p.q_bf16 = (const uint16_t*)a->q_bf16;
-  // The slot-pipelined mapping (mla_decode_fp8_x.hip): 128-row workgroups for rows > 64 (e.g. TP1, H=128); for 33..64 rows
-  // two compute waves + two loader waves (measured H=64: 102.5 vs 114 us; FLUENT_MLA_X_SMALL=0 keeps this file's kernel).
-  // At most 32 rows stay here: ONE slot-pipelined compute wave would carry all 40 MFMAs of a page on one SIMD (H=16:
-  // 85.8 us) where this file's two half-waves + two loaders take 78.3.  FLUENT_MLA_X=0: this file for every shape.
-  // fl_mla_num_parts sizes the scheduler's part count with the same rule.
-  // Role-specialised 64-row workgroups (mla_decode_fp8_y.hip): per-token FP8, more than 32 query rows per request.
-  // (both fp8 formats: the plain [.,576] cache is the kernel's FMT = 1 instantiation)
-  if (fl_mla_use_y() && p.rows > 32) return fl_mla_decode_fp8_y_impl(a, p, stream);
-  static const bool x_small = [] {
-    const char* e = getenv("FLUENT_MLA_X_SMALL");
-    return !(e != nullptr && e[0] == '0');
-  }();
-  if (fl_mla_use_x() && (p.rows > 64 || (x_small && p.rows > 32))) {
-    p.row_groups = (p.rows + 127) / 128;   // (recomputed by the callee from the rows)
-    return fl_mla_decode_fp8_x_impl(a, p, stream);
-  }
-  // rows <= 32 (e.g. the TP8 shard, H=16): one row group per workgroup (2 waves + 2 loaders); otherwise 2 row groups.
-  const int nrg = p.rows > 32 ? 2 : 1;
-  p.row_groups = (p.rows + 32 * nrg - 1) / (32 * nrg);
+  // More than 32 query rows per request: role-specialised 64-row workgroups (mla_decode_fp8_y.hip; both fp8 formats — the plain
+  // [.,576] cache is the kernel's FMT = 1 instantiation).  fl_mla_num_parts sizes the scheduler's part count with the same rule.
+  if (p.rows > 32) return fl_mla_decode_fp8_y_impl(a, p, stream);
+  // rows <= 32 (e.g. the TP8 shard, H=16): one 32-row group per workgroup (2 compute waves + 2 loader waves)
+  constexpr int nrg = 1;
+  p.row_groups = (p.rows + 31) / 32;
   const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(64 * (2 * nrg + loader_waves(nrg)));
 #define FL_LAUNCH(NRG_, FMT_)                                                                                          \
   mla_decode_fp8_kernel<NRG_, FMT_><<<grid, block, 0, stream>>>(                                                       \
       p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, a->num_splits, (const uint8_t*)a->k_nope,        \
       (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale)
-  if (per_token) {
-    if (nrg == 2) FL_LAUNCH(2, 0); else FL_LAUNCH(1, 0);
-  } else {
-    if (nrg == 2) FL_LAUNCH(2, 1); else FL_LAUNCH(1, 1);
-  }
+  if (per_token) FL_LAUNCH(1, 0);
+  else FL_LAUNCH(1, 1);
 #undef FL_LAUNCH
   FL_CHECK_LAUNCH("mla_decode_fp8_kernel");
   return fl_mla_launch_combine(p, a->num_splits, stream);
@@ -975,3 +953,20 @@ extern "C" int fl_mla_debug_set_buffer(int* dev_ptr) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &dev_ptr, sizeof(dev_ptr));
 }
 #endif
+
+// ---- fl_mla_decode — C-ABI dispatch over the KV-cache formats of MLATokenToKVPool (memory_pool.py:635-658) ----
+int fl_mla_decode_bf16_impl(const FlMlaDecodeArgs* a, hipStream_t stream);   // mla_decode_bf16.hip
+
+extern "C" int fl_mla_decode(const FlMlaDecodeArgs* args, fl_stream_t stream) {
+  FL_CHECK_ARG(args != nullptr, "fl_mla_decode: null args");
+  switch (args->kv_format) {
+    case FL_KV_FP8_PER_TOKEN:
+    case FL_KV_FP8_576:
+      return fl_mla_decode_fp8_impl(args, (hipStream_t)stream);
+    case FL_KV_BF16_576:
+      return fl_mla_decode_bf16_impl(args, (hipStream_t)stream);
+    default:
+      fl_set_error("fl_mla_decode: kv_format %d not implemented", args->kv_format);
+      return FL_ERR_UNSUPPORTED;
+  }
+}

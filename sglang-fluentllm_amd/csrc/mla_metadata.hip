@@ -125,10 +125,8 @@ __global__ __launch_bounds__(64) void mla_metadata_kernel(const int32_t* __restr
 
 extern "C" int fl_mla_num_parts(int cu_count, int rows_per_kv_head) {
   if (cu_count <= 0 || rows_per_kv_head <= 0) return 1;
-  // 128-row workgroups (mla_decode_fp8_x.hip, opt-in) ingest every KV byte once per 128 rows; else 32/64-row workgroups
-  // role-specialised 64-row workgroups (mla_decode_fp8_y.hip, default): 64 rows per workgroup for every shape
-  const int per_wg = fl_mla_use_y() ? FL_MLA_ROWS_PER_WG
-                     : (fl_mla_use_x() && rows_per_kv_head > FL_MLA_ROWS_PER_WG) ? fl_mla_x_rows_per_wg() : FL_MLA_ROWS_PER_WG;
+  // 64 query rows per workgroup for every shape (mla_decode_fp8_y.hip; at most 32 rows: ONE 32-row workgroup per part)
+  const int per_wg = FL_MLA_ROWS_PER_WG;
   const int row_groups = (rows_per_kv_head + per_wg - 1) / per_wg;
   const int parts = cu_count / row_groups;
   return parts > 0 ? parts : 1;

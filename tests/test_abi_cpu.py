@@ -29,11 +29,9 @@ def test_library_exports_all_declared_symbols():
     lib.fl_version.restype = ctypes.c_int
     assert lib.fl_version() >= 100
     lib.fl_mla_num_parts.restype = ctypes.c_int
-    # default: role-specialised 64-row workgroups (mla_decode_fp8_y.hip) -> CUs / ceil(rows / 64) parts;
-    # FLUENT_MLA_Y=0: 128-row workgroups for rows > 64 (FLUENT_MLA_X=0 on top: 64-row workgroups again)
-    legacy_x = os.environ.get("FLUENT_MLA_Y") == "0" and os.environ.get("FLUENT_MLA_X") != "0"
-    assert lib.fl_mla_num_parts(256, 128) == (256 if legacy_x else 128)
-    assert lib.fl_mla_num_parts(256, 256) == (128 if legacy_x else 64)
+    # 64-row workgroups for every shape (mla_decode_fp8_y.hip) -> CUs / ceil(rows / 64) parts
+    assert lib.fl_mla_num_parts(256, 128) == 128
+    assert lib.fl_mla_num_parts(256, 256) == 64
     assert lib.fl_mla_num_parts(256, 64) == 256 and lib.fl_mla_num_parts(256, 16) == 256
 
 

@@ -472,7 +472,7 @@ def test_masked_big_tile_vs_oracle():
 
 
 def test_big_tile_contiguous_and_dense_vs_oracle():
-    """>= 192 rows per group on average: the 256 x 256 tile kernel (grouped_gemm_fp8_big.hip) in contiguous mode (128-row
+    """>= 192 rows per group on average: the 256 x 256 tile kernel (grouped_gemm_fp8_big2.hip) in contiguous mode (128-row
     aligned groups, a group boundary INSIDE a 256-row tile span) and as the dense GEMM (M not a multiple of 256)."""
     import deep_gemm
 

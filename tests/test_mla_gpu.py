@@ -639,8 +639,7 @@ def test_flash_mla_with_kvcache_fp8(fm, lens, H, s_q, dq, dk):
     # query rows (mla_decode_fp8_y.hip, FMT = 1) keeps descale_k OUT of P' (scores carry dq*dk, the output is multiplied by
     # dk in the epilogue); the mapping for <= 32 rows folds log2(dk) into P' like the per-token format
     bsz = len(lens)
-    import os
-    y_map = s_q * H > 32 and os.environ.get("FLUENT_MLA_Y") != "0"
+    y_map = s_q * H > 32
     emu, _ = mla_ref.mla_decode_fp8_per_token_emulated(
         q[..., :512].contiguous(), torch.full((bsz, s_q, H, 1), dq * dk if y_map else dq), q[..., 512:].float(),
         kc[..., :512].contiguous().view(pages, 64, 1, 512), torch.full((pages, 64, 1, 1), 1.0 if y_map else dk),
