@@ -425,8 +425,9 @@ extern "C" int fl_bmm_bf16_nt(const void* A, const void* B, void* C, int batch, 
     const size_t lds = (size_t)n_per_wg * K * 2;
 #define FL_B2_LAUNCH(KS_, MT2_, BYM_)                                                                                          \
   do {                                                                                                                         \
-    static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&bmm_bf16_wlds_kernel<KS_, MT2_, BYM_>),  \
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kB2LdsBytes);              \
+    static std::atomic<unsigned char> done_[64];                                                                               \
+    const hipError_t attr_ = fl_set_max_dynamic_lds(reinterpret_cast<const void*>(&bmm_bf16_wlds_kernel<KS_, MT2_, BYM_>),      \
+                                                    kB2LdsBytes, done_);                                                        \
     FL_CHECK_ARG(attr_ == hipSuccess, "fl_bmm_bf16_nt: hipFuncSetAttribute(%d)", (int)attr_);                                  \
     bmm_bf16_wlds_kernel<KS_, MT2_, BYM_><<<grid, block, lds, s>>>(p, m_per_wg, n_per_wg);                                      \
   } while (0)
@@ -492,8 +493,8 @@ extern "C" int fl_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, int
   p.A = (const uint16_t*)A; p.B = (const uint16_t*)B; p.ws = (float*)workspace; p.C = C;
   p.M = (int)M; p.N = N; p.K = K; p.kc = K / ksplit; p.ksplit = ksplit; p.out_f32 = out_is_f32;
   p.sAm = a_stride_m; p.sBn = b_stride_n; p.sCm = c_stride_m;
-  static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&router_partial_kernel),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kB2LdsBytes);
+  static std::atomic<unsigned char> done_[64];
+  const hipError_t attr_ = fl_set_max_dynamic_lds(reinterpret_cast<const void*>(&router_partial_kernel), kB2LdsBytes, done_);
   FL_CHECK_ARG(attr_ == hipSuccess, "fl_gemm_bf16_nt_splitk: hipFuncSetAttribute(%d)", (int)attr_);
   hipStream_t s = (hipStream_t)stream;
   router_partial_kernel<<<dim3((unsigned)(tiles * ksplit)), dim3(256), (size_t)p.kc * 2 * 128, s>>>(p);

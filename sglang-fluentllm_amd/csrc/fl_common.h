@@ -133,3 +133,17 @@ __device__ __forceinline__ void fl_dma16_s(const void* sbase, const unsigned vof
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(fl_lds_addr(lds_dst)), "v"(voff), "s"(sbase)
                : "memory", "m0");
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: set once per (kernel, device) — a process that drives several
+// GPUs must not rely on a process-wide static.  `done` is the caller's per-kernel flag array (zero-initialised static).
+#include <atomic>
+inline hipError_t fl_set_max_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned char> (&done)[64]) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (done[dev].load(std::memory_order_acquire)) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done[dev].store(1, std::memory_order_release);
+  return e;
+}

@@ -314,8 +314,9 @@ extern "C" int fl_mla_absorb_rope_quant(const FlMlaAbsorbArgs* a, fl_stream_t st
   const size_t lds = kLdsBytes + 512;
 #define FL_ABSORB_LAUNCH(WN_)                                                                                                  \
   do {                                                                                                                         \
-    static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&mla_absorb_kernel<WN_>),                 \
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsBytes + 512));   \
+    static std::atomic<unsigned char> done_[64];                                                                               \
+    const hipError_t attr_ = fl_set_max_dynamic_lds(reinterpret_cast<const void*>(&mla_absorb_kernel<WN_>),                     \
+                                                    (int)(kLdsBytes + 512), done_);                                             \
     FL_CHECK_ARG(attr_ == hipSuccess, "fl_mla_absorb_rope_quant: hipFuncSetAttribute(%d)", (int)attr_);                        \
     mla_absorb_kernel<WN_><<<grid, block, lds, (hipStream_t)stream>>>(p);                                                       \
   } while (0)
