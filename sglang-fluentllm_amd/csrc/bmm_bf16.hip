@@ -391,20 +391,12 @@ extern "C" int fl_bmm_bf16_nt(const void* A, const void* B, void* C, int batch, 
   p.out_f32 = out_is_f32;
   p.ksplit = 1;
   // the absorption shapes (bf16 out, a 128-KiB weight matrix per batch): weights resident in LDS (bmm_bf16_wlds_kernel)
-  static const bool wlds_on = [] {
-    const char* e = getenv("FLUENT_BMM_WLDS");
-    return e == nullptr || e[0] == '\0' || atoi(e) != 0;
-  }();
-  if (wlds_on && !out_is_f32 && (K == 128 || K == 512) && (long long)N * K * 2 <= kB2LdsBytes && b_stride_n == K &&
+  if (!out_is_f32 && (K == 128 || K == 512) && (long long)N * K * 2 <= kB2LdsBytes && b_stride_n == K &&
       c_stride_m % 8 == 0 && c_stride_b % 8 == 0 && ((uintptr_t)C % 16) == 0 && b_stride_b % 8 == 0) {
     // at most 32 rows per batch: one 32-row token tile per workgroup, its n tiles over the 4 waves; more: a wave per token tile
     // (measured at T = 64, H = 128: 7.7 / 10.2 us by token tile vs 10.4 / 12.0 us by n tile).
     // The n slices per batch bring the launch to >= one workgroup per CU (a slice has >= 4 n tiles by-n, >= 1 by-m).
-    static const int bym_min = [] {   // experiment knob: rows per batch above which a wave owns a token tile
-      const char* e = getenv("FLUENT_BMM_BYM_MIN");
-      return e != nullptr && e[0] != '\0' ? atoi(e) : 32;
-    }();
-    const bool by_m = M > bym_min;
+    const bool by_m = M > 32;
     const long long wgs128 = (long long)batch * ((M + 127) / 128);
     const bool two = by_m && K == 128 && wgs128 > 512;   // plenty of workgroups: two token tiles per wave (half the LDS reads per flop)
     const int m_per_wg = by_m ? (two ? 256 : 128) : 32;

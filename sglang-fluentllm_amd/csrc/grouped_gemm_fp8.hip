@@ -354,20 +354,15 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
     return !(e != nullptr && e[0] == '0');
   }();
   // (contiguous groups are only 128-row aligned; the big tile addresses a weight panel with 32-bit offsets)
-  static const long long big_min = [] {
-    const char* e = getenv("FLUENT_GEMM_BIG_MIN_ROWS");
-    return e != nullptr ? atoll(e) : 128ll;   // (measured, E = 256 top-8: 128 rows per expert: w13 872 vs 871, w2 816 vs 873 TFLOP/s with the
-                                              //  256 x 256 kernel; 64 rows per expert: 559 vs 459 — the 128-row kernel stays below 128)
-  }();
+  // (measured, E = 256 top-8: 128 rows per expert: w13 872 vs 871, w2 816 vs 873 TFLOP/s with the 256 x 256 kernel; 64 rows per expert:
+  //  559 vs 459 — the 128-row kernel stays below 128)
+  constexpr long long big_min = 128;
   p.ksplit = 1;
   p.ws = nullptr;
   // Dense GEMMs with few rows (decode projections; a workspace is present): the token-tile height follows the weight
   // bytes — measured (tools/bench_dense.py): <= 8 MB 32-token tiles, <= 32 MB 64-token tiles (3-stage rings, 2
   // workgroups per CU), else 128-token tiles (fewer re-reads of W through L2); split-K fills the chip
-  static const int dense_mt = [] {   // experiment knob
-    const char* e = getenv("FLUENT_GEMM_DENSE_MT");
-    return e != nullptr ? atoi(e) : 0;
-  }();
+  constexpr int dense_mt = 0;
   if (a->mode == kDense && a->workspace != nullptr) {
     const long long wb = (long long)a->N * a->K;
     const int want = dense_mt > 0 ? dense_mt : (wb <= (8ll << 20) ? 1 : (wb <= (32ll << 20) ? 2 : 4));

@@ -517,13 +517,9 @@ int fl_gemm_launch_big2(const GemmParams& p_in, const void* A, const float* As, 
   FL_CHECK_ARG(p.N < (1 << 24) && p.K < (1 << 24) && (long long)p.N * p.K < (1ll << 32),
                "fl_grouped_gemm_fp8: N*K too large for the 256x256 tile");
   p.total_blocks = (int)blocks;
-  // one workgroup per CU walks the tile list (FLUENT_GEMM_PERSIST=0: one workgroup per tile, for A/B runs)
-  static const bool persist = [] {
-    const char* e = getenv("FLUENT_GEMM_PERSIST");
-    return !(e != nullptr && e[0] == '0');
-  }();
+  // one workgroup per CU walks the tile list
   long long grid = blocks;
-  if (persist) {
+  {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && fl_device_cu_count(dev, &cus) == FL_OK && cus > 0 && grid > cus) grid = cus;
   }

@@ -278,11 +278,7 @@ extern "C" int fl_mla_quant_q_store_k(const void* key, int64_t n_k, const int32_
   // Measured (MI355X, tools/time_quant.py, bs = 128 x H = 128 + 128 K rows = 29.5 MB moved): wave per row, 2 rows per wave 9.4-9.6 us;
   // 4 rows per wave 11.0; 16 lanes per row 9.0 (3.3 TB/s), two passes per wave 10.6.  Decode-sized launches (bs 1 / 16: 3.0 / 3.6 us,
   // launch-bound) stay on the wave-per-row form (16 lanes per row: 3.5 / 3.7 us).
-  static const int form_env = [] {   // experiment knob: 1 / 2 = wave per row with that many rows per wave, 16 = 16 lanes per row
-    const char* e = getenv("FLUENT_QK_FORM");
-    return e != nullptr ? atoi(e) : 0;
-  }();
-  const int form = form_env > 0 ? form_env : (n >= 8192 ? 16 : 1);
+  const int form = n >= 8192 ? 16 : 1;
 #define FL_QK_ARGS                                                                                                                 \
   (const uint16_t*)key, n_k, indices, (uint8_t*)k_lora_cache, k_scale_cache, (uint16_t*)k_rope_cache, num_slots, (const uint16_t*)q, \
       q_rows, (uint8_t*)q_nope, q_scale, (uint16_t*)q_rope

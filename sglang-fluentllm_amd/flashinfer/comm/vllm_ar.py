@@ -5,7 +5,7 @@ The reference's implementation registers cudaIpc-mapped buffers of all peers and
 driver `CustomAllreduce` needs `CudaRTLibrary` (libcudart through ctypes, custom_all_reduce.py:18,212-229) for the handle
 exchange — absent on ROCm — and is disabled there (`--disable-custom-all-reduce`; `GroupCoordinator.all_reduce` then uses
 pynccl = RCCL, parallel_state.py).  This module keeps the ENTRY POINTS with the reference's signatures; behind them:
-  * decode-sized bf16 inputs ([rows <= FLUENT_AR_ONESHOT_TOKENS (256), H <= 8192], the shape of the hidden states the
+  * decode-sized bf16 inputs ([rows <= 256, H <= 8192], the shape of the hidden states the
     reference's custom all-reduce serves) run as ONE peer-mapped one-shot kernel (csrc/comm_oneshot.hip: the same transport
     as the fused C5 — fl_allreduce_fused with no residual and no norm is a plain one-shot sum; the workspace and the hipIpc
     mappings are set up by `init_custom_ar`, a collective call like the reference's);
@@ -44,7 +44,7 @@ def _make_oneshot(group):
 
     try:
         return OneShotComm(dist.get_rank(group) if multi else 0, world if multi else 1,
-                           int(os.environ.get("FLUENT_AR_ONESHOT_TOKENS", "256")), 8192, group=group)
+                           256, 8192, group=group)
     except RuntimeError as ex:
         import warnings
 
