@@ -245,6 +245,12 @@ int fl_reducescatter_fused(void* comm, const void* in, int64_t T, int H, const v
 int fl_allgather_fused(void* comm, const void* in, int64_t t_cur, int64_t T, int D, void* out, int q_rank, int kv_rank,
                        const void* gamma_q, const void* gamma_kv, float eps_q, float eps_kv, void* x_norm_out, void* quant_out,
                        float* scale_out, int64_t s_stride_t, int64_t s_stride_g, fl_stream_t stream);
+/* C1 / C2 exchange on the same transport (eps.fast_ep.AllToAll over MSCCL++: srt/layers/moe/dispatcher/fast_ep.py:45-78,
+ * distributed/parallel_state.py:965-977): equal-split all-to-all of `world` slabs of `cap` rows x D 2-byte elements — slab p of `send`
+ * lands as slab `rank` of rank p's `recv`.  ids_col >= 0: a row's top_k int32 expert ids start at element ids_col of the row; rows whose
+ * ids are all negative (nobody routed there) travel and are copied out as their 16-byte-aligned tail only.  cap * world <= 1024,
+ * cap <= max_tokens, D <= hidden of the communicator. */
+int fl_alltoall_oneshot(void* comm, const void* send, void* recv, int cap, int D, int ids_col, int top_k, fl_stream_t stream);
 int fl_comm_check(void* comm /*synchronises; FL_ERR_LAUNCH if a flag wait ever timed out*/);
 int fl_comm_destroy(void* comm);
 /* The same protocol on plain host memory (shared-memory workspaces of several processes): drives the CPU-side protocol

@@ -263,6 +263,104 @@ __global__ __launch_bounds__(256) void oneshot_ag_kernel(const Peers peers, cons
   }
 }
 
+
+// C1 / C2 exchange as ONE kernel: the equal-split all-to-all of eps.fast_ep.AllToAll's peer slabs (fast_ep.py:45-78; the reference's
+// AllToAll sits on an MSCCL++ communicator, distributed/parallel_state.py:965-977) on the peer-mapped transport instead of an RCCL
+// all_to_all_single.  `send` holds `world` slabs of `cap` rows of D 2-byte elements (slab p goes to rank p); `recv` gets slab s from
+// rank s.  Workgroup (p, r) pushes row r of slab p into rank p's inbox[parity][rank][r], raises that row's flag there, then waits for
+// the flag of the row rank p sent HERE as its row r and copies it out — every workgroup is sender and receiver of one row, nobody waits
+// for a grid.  A decode step's slabs are mostly empty rows (a token occupies one row per peer it routes to): with ids_col >= 0 the K
+// int32 expert ids in a row's tail say so (all < 0), and only the tail of such a row travels and is copied out.
+__global__ __launch_bounds__(256) void oneshot_a2a_kernel(const Peers peers, const int rank, const FlCommLayout L,
+                                                          const uint16_t* __restrict__ send, uint16_t* __restrict__ recv, const int cap,
+                                                          const int D, const int ids_col /*in 2-byte elements, -1: none*/, const int K,
+                                                          const unsigned long long budget, unsigned* __restrict__ host_err) {
+  __shared__ unsigned s_epoch;
+  __shared__ int s_fail;
+  __shared__ unsigned s_dead;
+  __shared__ int s_live;
+  uint8_t* me = peers.ws[rank];
+  FlCommState* st = reinterpret_cast<FlCommState*>(me);
+  const int tid = threadIdx.x;
+  const int W = L.world;
+  if (tid == 0) {
+    s_epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_dead = __hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    s_fail = 0;
+  }
+  __syncthreads();
+  const unsigned e = s_epoch;
+  const int par = (int)(e & 1u);
+  const long long b = blockIdx.x;
+  const long long rows = (long long)W * cap;
+  const int p = (int)(b / cap), r = (int)(b % cap);
+  // columns a row moves: everything, or (a row nobody routed to) the 16-byte-aligned span that holds its ids
+  const int tail_lo = ids_col >= 0 ? (ids_col / 8) * 8 : 0;
+  auto row_is_live = [&](const uint16_t* row) -> bool {   // (uniform per workgroup: thread 0 decides)
+    if (ids_col < 0) return true;
+    if (tid == 0) {
+      const int32_t* ids = reinterpret_cast<const int32_t*>(row + ids_col);
+      int live = 0;
+      for (int k = 0; k < K; ++k) live |= ids[k] >= 0 ? 1 : 0;
+      s_live = live;
+    }
+    __syncthreads();
+    const bool v = s_live != 0;
+    __syncthreads();
+    return v;
+  };
+  auto poison = [&]() {
+    const uint4 nan16 = make_uint4(0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u);
+    for (int col = tid * 8; col < D; col += 256 * 8) *reinterpret_cast<uint4*>(recv + b * D + col) = nan16;
+  };
+  if (s_dead != 0u) {
+    if (b < rows) poison();
+    return;
+  }
+  if (b < rows) {
+    const uint16_t* src = send + b * D;
+    const bool live = row_is_live(src);
+    uint16_t* dst = reinterpret_cast<uint16_t*>(peers.ws[p] + fl_comm_inbox_offset(L)) + fl_comm_inbox_row(L, par, rank, r);
+    for (int col = (live ? 0 : tail_lo) + tid * 8; col < D; col += 256 * 8)
+      *reinterpret_cast<uint4*>(dst + col) = *reinterpret_cast<const uint4*>(src + col);
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+      store_flag(peers.ws[p], fl_comm_flag_index(L, par, rank, r), e);
+      if (!wait_flag(me, fl_comm_flag_index(L, par, p, r), e, budget)) s_fail = 1;
+    }
+    __syncthreads();
+    if (!s_fail) {
+      const uint16_t* in = reinterpret_cast<const uint16_t*>(me + fl_comm_inbox_offset(L)) + fl_comm_inbox_row(L, par, p, r);
+      const bool got = row_is_live(in);
+      for (int col = (got ? 0 : tail_lo) + tid * 8; col < D; col += 256 * 8)
+        *reinterpret_cast<uint4*>(recv + b * D + col) = *reinterpret_cast<const uint4*>(in + col);
+    }
+  } else if (tid < W) {   // the sync row: nobody starts operation e + 2 before every peer has finished e (comm_protocol.h)
+    store_flag(peers.ws[tid], fl_comm_flag_index(L, par, W, rank), e);
+    if (!wait_flag(me, fl_comm_flag_index(L, par, W, tid), e, budget)) s_fail = 1;
+  }
+  __syncthreads();
+  if (s_fail) {
+    if (tid == 0) {
+      __hip_atomic_store(&st->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (b < rows) poison();
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    const unsigned old = atomicAdd(&st->arrive, 1u);
+    if (old == gridDim.x - 1) {
+      st->arrive = 0;
+      __threadfence();
+      if (__hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u)
+        __hip_atomic_store(&st->epoch, e + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 int launch(FlComm* c, bool rs, const void* in, int64_t T, int H, const void* add_in, const void* residual_in, const void* gamma,
            float eps, void* residual_out, void* norm_out, void* quant_out, float* scale_out, int64_t ss_t, int64_t ss_g,
            fl_stream_t stream) {
@@ -448,6 +546,30 @@ extern "C" int fl_allgather_fused(void* comm, const void* in, int64_t t_cur, int
       (const uint16_t*)gamma_kv, eps_q, eps_kv, (uint16_t*)x_norm_out, (uint8_t*)quant_out, scale_out, s_stride_t, s_stride_g, budget,
       c->host_err_dev);
   FL_CHECK_LAUNCH("oneshot_ag_kernel");
+  return FL_OK;
+}
+
+extern "C" int fl_alltoall_oneshot(void* comm, const void* send, void* recv, int cap, int D, int ids_col, int top_k, fl_stream_t stream) {
+  FlComm* c = (FlComm*)comm;
+  FL_CHECK_ARG(c != nullptr && c->connected, "one-shot comm: not connected (fl_comm_connect)");
+  if (__atomic_load_n(c->host_err, __ATOMIC_RELAXED) != 0u) {
+    fl_set_error("one-shot comm: an earlier launch timed out waiting for a peer (rank %d of %d); the communicator is dead, "
+                 "its outputs since then are NaN — re-create it", c->rank, c->world);
+    return FL_ERR_LAUNCH;
+  }
+  FL_CHECK_ARG(cap >= 1 && cap <= c->L.max_tokens && (long long)cap * c->world <= kMaxOneShotTokens,
+               "one-shot all-to-all: %d rows per peer x %d ranks exceed the workspace (max_tokens %lld, %lld rows per launch)", cap, c->world,
+               c->L.max_tokens, kMaxOneShotTokens);
+  FL_CHECK_ARG(D > 0 && D % 8 == 0 && D <= c->L.hidden, "one-shot all-to-all: D=%d (workspace hidden %d)", D, c->L.hidden);
+  FL_CHECK_ARG(send != nullptr && recv != nullptr && send != recv, "one-shot all-to-all: null or aliased buffers");
+  FL_CHECK_ARG(ids_col < 0 || (top_k >= 1 && ids_col % 2 == 0 && ids_col + 2 * top_k <= D),
+               "one-shot all-to-all: the %d expert ids at element %d do not fit a row of %d", top_k, ids_col, D);
+  Peers peers;
+  for (int p = 0; p < kMaxWorld; ++p) peers.ws[p] = p < c->world ? c->peer[p] : nullptr;
+  const unsigned long long budget = (unsigned long long)(c->timeout_s * 1e8);
+  oneshot_a2a_kernel<<<dim3((unsigned)(cap * c->world) + 1), 256, 0, (hipStream_t)stream>>>(
+      peers, c->rank, c->L, (const uint16_t*)send, (uint16_t*)recv, cap, D, ids_col, top_k, budget, c->host_err_dev);
+  FL_CHECK_LAUNCH("oneshot_a2a_kernel");
   return FL_OK;
 }
 

@@ -15,6 +15,10 @@ of a rank routes to the same peer — instead of `max_tokens_per_rank * top_k` r
   combine : rows [world*cap, hidden] back — ONE all_to_all_single when the weights went out with the dispatch; otherwise (the
             reference's call order: `AllToAll.dispatch` is not given the weights, fast_ep.py:45-51) the weights follow as a second,
             32 B/row message at combine time, as before
+Transport (round 4): with RCCL ("nccl") groups on the GPU and decode-sized slabs (world * cap <= 1024 rows) each of these messages is
+ONE launch of the peer-mapped one-shot transport (csrc/comm_oneshot.hip: oneshot_a2a_kernel — rows pushed straight into the peers'
+inboxes over their xGMI links, per-row flags, empty slab rows travel as their 64-byte tail only) and no RCCL call, like C3-C7; larger
+slabs, other backends and FLUENT_ONESHOT=0 keep the RCCL all_to_all_single.  `comm_route` names the route taken.
 The integer / row work around the exchanges runs in HIP kernels (csrc/ep_a2a.hip).  `row_ops` exists so that the
 multi-process HOST logic can be exercised on CPU tensors with the gloo backend in tests (tests/ inject a torch-indexing
 implementation); the product default is the HIP one and there is no automatic fallback."""
@@ -126,16 +130,48 @@ class AllToAll:
         self.row_ops = row_ops if row_ops is not None else HipRowOps()
         self._state = None
         self._ones = None
+        # decode-sized exchanges on the peer-mapped one-shot transport (collective, all-or-nothing construction like TPDPConvertor's:
+        # every rank builds its AllToAll at the same point of start-up, fast_ep.py:16-22); FLUENT_ONESHOT=0 disables, =1 also builds it
+        # at world 1 (tests)
+        import os
+
+        self.oneshot = None
+        self.messages = {"oneshot": 0, "rccl": 0}                 # launches per route (tests, bench `comm_route`)
+        want = os.environ.get("FLUENT_ONESHOT", "auto")
+        multi = dist.is_initialized() and self.world > 1 and dist.get_backend(group) == "nccl"
+        tail = (4 * self.top_k + 7) // 8 * 8
+        if row_ops is None and want != "0" and torch.cuda.is_available() and (multi or want == "1") \
+                and self.world * self.cap <= 1024 and self.hidden + tail <= 8192 and self.hidden % 8 == 0:
+            from .oneshot import OneShotComm
+            try:
+                self.oneshot = OneShotComm(self.rank if multi else 0, self.world if multi else 1, self.cap, self.hidden + tail, group=group)
+            except RuntimeError as ex:
+                import warnings
+
+                warnings.warn(f"fluent_mi355: one-shot EP exchange unavailable ({ex}); using RCCL all_to_all_single")
+
+    @property
+    def comm_route(self):
+        return "one-shot peer-mapped kernel (rows pushed into the peers' inboxes)" if self.oneshot is not None else \
+            "RCCL all_to_all_single"
 
     def slab_bytes(self, dtype_size=2):
         """bytes one rank puts on the wire per direction (rows only)"""
         return self.world * self.cap * self.hidden * dtype_size
 
-    def _a2a(self, inp):
+    def _a2a(self, inp, ids_col=-1):
+        """slab p of `inp` -> slab `rank` of rank p's result.  ids_col (dispatch message): 2-byte-element index of the row's expert ids"""
+        if self.oneshot is not None and inp.is_cuda:
+            out = torch.empty_like(inp)
+            if self.oneshot.accepts_alltoall(inp, out, self.cap):
+                self.oneshot.alltoall(inp, out, self.cap, ids_col, self.top_k if ids_col >= 0 else 0)
+                self.messages["oneshot"] += 1
+                return out
         if self.world == 1:
             return inp                                            # one rank: the slab it sends is the slab it receives
         out = torch.empty_like(inp)
         dist.all_to_all_single(out, inp, group=self.group)       # equal splits: world slabs of `cap` rows
+        self.messages["rccl"] += 1
         return out
 
     def _message(self, dtype, device):
@@ -176,7 +212,7 @@ class AllToAll:
         else:
             self.row_ops.route_dedup(idx, K, self.experts_per_rank, W, self.cap, tok_slot, send_eid, pair_src)
         self.row_ops.send(dp_x.contiguous(), tok_slot, W, send_rows)              # empty rows: never read (all their ids are -1)
-        recv = self._a2a(msg)                                                     # ONE message: rows + ids (+ weights)
+        recv = self._a2a(msg, ids_col=self.hidden)                                # ONE message: rows + ids (+ weights)
         h2 = self.hidden // 2
         recv_rows, recv_eid = recv[:, :self.hidden], recv.view(torch.int32)[:, h2:h2 + K]
         recv_w = recv.view(torch.float32)[:, h2 + K:h2 + 2 * K] if weights is not None else None

@@ -26,6 +26,8 @@ lib.fl_comm_set_timeout.argtypes = [_vp, ctypes.c_double]
 lib.fl_allreduce_fused.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i64, _vp]
 lib.fl_reducescatter_fused.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i64, _vp]
 lib.fl_allgather_fused.argtypes = [_vp, _vp, _i64, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i64, _i64, _vp]
+lib.fl_alltoall_oneshot.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
+lib.fl_alltoall_oneshot.restype = _i32
 lib.fl_comm_check.argtypes = [_vp]
 lib.fl_comm_destroy.argtypes = [_vp]
 for _n in ("fl_comm_create", "fl_comm_local_handle", "fl_comm_connect", "fl_comm_set_timeout", "fl_allreduce_fused",
@@ -188,6 +190,24 @@ class OneShotComm:
         check(lib.fl_allgather_fused(self._h, x.data_ptr() if x.numel() else None, x.shape[0], int(total), x.shape[1], out.data_ptr(),
                                      int(q_rank), int(kv_rank), _p(gamma_q), _p(gamma_kv), float(eps_q), float(eps_kv),
                                      _p(x_norm_out), _p(quant_out), _p(scale_out), st, sg, stream_ptr(x.device)), "fl_allgather_fused")
+
+    def accepts_alltoall(self, send, recv, cap):
+        """raw-pointer contract of alltoall: two distinct contiguous device tensors [world * cap, X] of one dtype whose rows are a
+        multiple of 16 bytes and fit the workspace rows; cap rows per peer fit the inbox and one launch"""
+        if send.dim() != 2 or not send.is_cuda or not send.is_contiguous() or recv.shape != send.shape or recv.dtype != send.dtype \
+                or recv.device != send.device or not recv.is_contiguous() or recv.data_ptr() == send.data_ptr():
+            return False
+        row_bytes = send.shape[1] * send.element_size()
+        return (send.shape[0] == self.world * cap and 1 <= cap <= self.max_tokens and cap * self.world <= MAX_ONESHOT_TOKENS
+                and row_bytes % 16 == 0 and row_bytes <= 2 * self.hidden)
+
+    def alltoall(self, send, recv, cap, ids_col=-1, top_k=0):
+        """equal-split all-to-all of `world` slabs of `cap` rows (slab p of `send` -> slab `rank` of rank p's `recv`), one launch.
+        ids_col: index (in 2-byte elements) of a row's top_k int32 expert ids, or -1; rows with no id >= 0 move their tail only."""
+        self._require(self.accepts_alltoall(send, recv, cap), "alltoall")
+        D = send.shape[1] * send.element_size() // 2
+        check(lib.fl_alltoall_oneshot(self._h, send.data_ptr(), recv.data_ptr(), int(cap), int(D), int(ids_col), int(top_k),
+                                      stream_ptr(send.device)), "fl_alltoall_oneshot")
 
     def check(self):
         """synchronises; raises if a flag wait ever timed out (a peer died or issued a different sequence of operations)"""

@@ -260,6 +260,66 @@ def test_oneshot_two_processes_on_one_gpu_hipipc():
     assert r.stdout.count("parity OK") == 2, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_ep_exchange_on_the_oneshot_transport_between_processes_on_one_gpu(world):
+    """C1 / C2 (eps.fast_ep.AllToAll.dispatch / combine) with every exchange ONE launch of the peer-mapped transport
+    (oneshot_a2a_kernel: rows pushed into the peers' hipIpc-mapped inboxes, per-row flags, empty slab rows as their 64-byte tail):
+    2 and 3 processes on the one GPU, bit-identical to the same host logic + row kernels with the exchange staged through a gloo
+    all_to_all_single — random routing, a third of the capacity, every token to one peer (full slab), with and without the routing
+    weights in the dispatch message; no RCCL call is counted."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "oneshot_two_procs.py"), str(world), "ep"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("one-shot transport OK") == world, r.stdout[-2000:]
+
+
+def test_ep_exchange_world1_oneshot_route_matches_the_plain_route(monkeypatch):
+    """FLUENT_ONESHOT=1 builds the communicator at world 1: dispatch / combine then run through oneshot_a2a_kernel (a self-push through
+    the inbox) and must give the bytes of the world-1 plain route (the slab a rank sends is the slab it receives), also when replayed
+    from a hipGraph (the epoch lives in device memory)."""
+    from eps.fast_ep import AllToAll
+    E, K, HID, t = 32, 8, 7168, 29
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(t, HID, generator=g).to(torch.bfloat16).to(DEV)
+    idx = torch.stack([torch.randperm(E, generator=g)[:K] for _ in range(t)]).to(torch.int32).to(DEV)
+    w = torch.rand(t, K, generator=g).to(DEV)
+
+    def run(a2a):
+        ex = torch.zeros(E + 1, dtype=torch.int32, device=DEV)
+        xr = torch.zeros(a2a.cap * K, HID, dtype=torch.bfloat16, device=DEV)
+        a2a.dispatch(ex, xr, x, idx, t, weights=w)
+        y = (xr.float() * 0.5 - 1.0).to(torch.bfloat16)
+        out = torch.zeros(t, HID, dtype=torch.bfloat16, device=DEV)
+        a2a.combine(out, w, y, t)
+        return out, ex
+
+    plain = AllToAll(K, E, HID, 32, None)
+    assert plain.oneshot is None
+    monkeypatch.setenv("FLUENT_ONESHOT", "1")
+    one = AllToAll(K, E, HID, 32, None)
+    assert one.oneshot is not None and "one-shot" in one.comm_route
+    o0, e0 = run(plain)
+    o1, e1 = run(one)
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1) and torch.equal(e0, e1)
+    assert one.messages == {"oneshot": 2, "rccl": 0}
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run(one)
+    torch.cuda.current_stream().wait_stream(s)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        o2, _ = run(one)
+    for _ in range(3):
+        gr.replay()
+    torch.cuda.synchronize()
+    one.oneshot.check()
+    assert torch.equal(o2, o0)
+
+
 def test_oneshot_allgather_and_dual_rmsnorm_world1_match_the_collective_route(monkeypatch):
     """C7 / C3 on the one-shot transport at world 1 (FLUENT_ONESHOT=1): flashinfer.comm.trtllm_allgather_fusion (gather only, and
     gather + dual RMSNorm + fp8 quant) and TPDPConvertor.reduce_scatter / all_gather give the bits of the RCCL-route kernels;

@@ -277,7 +277,7 @@ def build(dev, world, rank, group, layers, seq=SEQ, bs=BS, seed=0, realistic=Fal
                 xgmi_send_bytes_per_layer=xgmi, query_side="A2 one launch (bmm + RoPE + K5 + K4)" if USE_A2 else "bmm, RoPE, K5, K4 (four launches)",
                 data_connected=True, shared_expert="second stream",
                 comm_route={"allgather / reducescatter (<= 1024 tokens)": "one-shot peer-mapped kernel" if getattr(h_tp[0], "oneshot", None) is not None
-                            else "RCCL collective + fused kernel", "ep_dispatch / ep_combine": "ONE RCCL all_to_all_single each (ids + weights in the slab-row tail)"})
+                            else "RCCL collective + fused kernel", "ep_dispatch / ep_combine": a2a.comm_route + ", ONE message each (ids + weights in the slab-row tail)"})
     # everything a checker needs to recompute the layer from its inputs (tests/test_cfg4_gpu.py); not used by the bench
     info["_state"] = dict(W=W, B=B, wl=wl, hid_loc=hid_loc, meta=meta, ns=ns, res_in=B["res"].clone(), positions=positions, cache=cache)
     info["_layer"] = layer

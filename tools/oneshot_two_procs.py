@@ -66,6 +66,79 @@ def worker(rank, world, port, T, H, iters):
         raise SystemExit(1)
 
 
+def ep_worker(rank, world, port, tokens, hidden, iters):
+    """C1 / C2 on the one-shot transport: eps.fast_ep.AllToAll.dispatch -> per-expert op -> combine between `world` processes on one
+    GPU, every exchange ONE oneshot_a2a_kernel launch over hipIpc-mapped inboxes, against the SAME host logic and row kernels with the
+    exchange staged through a gloo all_to_all_single on the CPU: bit-identical outputs (only the transport differs)."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from fluent_mi355.ep import AllToAll
+    from fluent_mi355.oneshot import OneShotComm
+    K, E = 8, 32 * world
+    el = E // world
+
+    def gloo_a2a(self, inp, ids_col=-1):
+        src = inp.cpu().contiguous()
+        out = torch.empty_like(src)
+        dist.all_to_all_single(out, src)
+        self.messages["rccl"] += 1
+        return out.to(inp.device)
+
+    a_one = AllToAll(K, E, hidden, tokens * world, None)
+    a_one.oneshot = OneShotComm(rank, world, a_one.cap, hidden + (4 * K + 7) // 8 * 8, timeout_s=10.0)
+    a_ref = AllToAll(K, E, hidden, tokens * world, None)
+    a_ref._a2a = gloo_a2a.__get__(a_ref)
+    ok = True
+    rows = world * a_one.cap * K
+    for it in range(iters):
+        g = torch.Generator().manual_seed(1000 * it + rank)
+        t = tokens if it % 3 else max(1, tokens // 3)             # fewer tokens than the capacity: mostly empty slabs
+        x = torch.randn(t, hidden, generator=g).to(torch.bfloat16).to(dev)
+        ids = torch.stack([torch.randperm(E, generator=g)[:K] for _ in range(t)]).to(torch.int32)
+        if it == 1:
+            ids = (torch.arange(K, dtype=torch.int32) + el * ((rank + 1) % world)).repeat(t, 1)    # every token to ONE peer: full slab
+        ids = ids.to(dev)
+        w = torch.rand(t, K, generator=g).to(dev)
+        outs = []
+        for a, with_w in ((a_one, True), (a_ref, True), (a_one, False), (a_ref, False)):
+            ex = torch.zeros(el + 1, dtype=torch.int32, device=dev)
+            xr = torch.zeros(rows, hidden, dtype=torch.bfloat16, device=dev)
+            a.dispatch(ex, xr, x, ids, t * world, weights=w if with_w else None)
+            y = (xr.float() * 1.5 + 0.25).to(torch.bfloat16)        # stands in for the expert MLPs (row-wise, routing-independent)
+            out = torch.zeros(t, hidden, dtype=torch.bfloat16, device=dev)
+            a.combine(out, w, y, t * world)
+            torch.cuda.synchronize()
+            outs.append((out.clone(), ex.clone()))
+        a_one.oneshot.check()
+        ok &= torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        ok &= torch.equal(outs[2][0], outs[3][0]) and torch.equal(outs[0][0], outs[2][0])
+        # and against plain arithmetic: out[t] = sum_k w[t,k] * (1.5 x[t] + 0.25), rounded once per (token, rank) + once at home
+        want = (w.sum(1, keepdim=True) * (x.float() * 1.5 + 0.25).to(torch.bfloat16).float())
+        ok &= bool(((outs[0][0].float() - want).abs() <= 0.03 * want.abs() + 0.05).all())
+    ok &= a_one.messages["rccl"] == 0 and a_one.messages["oneshot"] == iters * (2 + 3)   # with weights: 2 launches per layer; without: 3
+    # latency of one dispatch-sized exchange (msg rows + tail) on the transport alone
+    msg = torch.zeros(world * a_one.cap, hidden + 32, dtype=torch.bfloat16, device=dev)
+    msg.view(torch.int32)[:, hidden // 2:hidden // 2 + K] = 1
+    out = torch.empty_like(msg)
+    for _ in range(3): a_one.oneshot.alltoall(msg, out, a_one.cap, hidden, K)
+    torch.cuda.synchronize(); dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): a_one.oneshot.alltoall(msg, out, a_one.cap, hidden, K)
+    e1.record(); torch.cuda.synchronize()
+    a_one.oneshot.check()
+    print(f"rank {rank}/{world}: EP dispatch/combine on the one-shot transport {'OK' if ok else 'MISMATCH'} over {iters} iterations "
+          f"({a_one.messages}); all-to-all of {world} x {a_one.cap} full rows x {hidden + 32} bf16: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us/op "
+          f"(processes sharing one GPU)", flush=True)
+    dist.barrier()
+    a_one.oneshot.close()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
 def lost_peer_worker(rank, world, port, T, H):
     """rank 1 skips one operation: rank 0's wait runs out of its (here 1 s) budget.  Required behaviour: the
     failing launch leaves NaN in every output row, never partial sums; the epoch does not advance; the next launch call
@@ -176,6 +249,8 @@ if __name__ == "__main__":
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     if len(sys.argv) > 2 and sys.argv[2] == "lostpeer":
         mp.spawn(lost_peer_worker, args=(2, port, 16, 2048), nprocs=2, join=True)
+    elif len(sys.argv) > 2 and sys.argv[2] == "ep":
+        mp.spawn(ep_worker, args=(world, port, 32, 7168, 6), nprocs=world, join=True)
     elif len(sys.argv) > 2 and sys.argv[2] == "k1":
         mp.spawn(beside_k1_worker, args=(2, port, 48, 7168), nprocs=2, join=True)
     else:
