@@ -43,7 +43,7 @@ def _worker(rank, world, port, t_per_rank, one_peer=False, weights_at_dispatch=F
         expert_x = torch.zeros(T_g * K, HID, dtype=torch.bfloat16)
         sent = []
         orig_a2a = a2a._a2a
-        a2a._a2a = lambda inp: (sent.append(tuple(inp.shape)), orig_a2a(inp))[1]      # count the messages of each direction
+        a2a._a2a = lambda inp, ids_col=-1: (sent.append(tuple(inp.shape)), orig_a2a(inp, ids_col))[1]      # count the messages of each direction
         a2a.dispatch(out_exclusive_sum=ex, out_expert_x=expert_x, dp_x=x, indices=idx, num_global_tokens=T_g,
                      **({"weights": w} if weights_at_dispatch else {}))
         assert len(sent) == 1 and sent[0][1] == HID + 16, sent                          # ONE dispatch message: row + 3 ids + 3 weights, 16-B rounded
