@@ -478,11 +478,12 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     }
   }
 #ifdef FL_GEMM2_TIMING
+  const unsigned long long t_epi_issued = __builtin_readcyclecounter();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (g_g2dbg != nullptr && lane == 0 && slot < 8192) {
     unsigned long long* d = g_g2dbg + ((long long)slot * 8 + wave) * 8;
     d[0] = gt[0]; d[1] = gt[1]; d[2] = gt[2]; d[3] = gt[3]; d[4] = t_loop_end - g0;
-    d[5] = g0 - t_entry;                                   // tile lookup + address set-up
+    d[5] = t_epi_issued - t_loop_end;                       // epilogue: instructions issued (stores not yet acknowledged)
     d[6] = __builtin_readcyclecounter() - t_loop_end;      // epilogue incl. the wait for its stores
     d[7] = w_entry;                                        // wall clock (100 MHz) at entry: workgroup start times
   }

@@ -9,7 +9,7 @@ import torch, numpy as np
 import deep_gemm
 from fluent_mi355._lib import lib
 dev = torch.device("cuda:0")
-E, N, K, R = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 4096, int(sys.argv[2]) if len(sys.argv) > 2 else 7168, 512
+E, N, K, R = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 4096, int(sys.argv[2]) if len(sys.argv) > 2 else 7168, int(os.environ.get("GT_ROWS", "512"))
 g = torch.Generator(device=dev).manual_seed(0)
 W = torch.randint(0, 120, (E, N, K), device=dev, generator=g, dtype=torch.uint8).view(torch.float8_e4m3fn)
 Ws = torch.rand(E, N // 128, K // 128, device=dev, generator=g) * 1e-2
@@ -39,7 +39,7 @@ nwg = d.shape[0]
 w = d[:, 0, 7]
 starts = np.sort(w - w.min()) / 100.0   # us
 rounds = max(1, nwg // 256)
-print(f"workgroups {nwg}: set-up {x[:,5].mean():.0f} cycles, k loop {x[:,4].mean():.0f}, epilogue {x[:,6].mean():.0f} (max {x[:,6].max():.0f}); "
+print(f"workgroups {nwg}: epilogue issue {x[:,5].mean():.0f} cycles, k loop {x[:,4].mean():.0f}, epilogue {x[:,6].mean():.0f} (max {x[:,6].max():.0f}); "
       f"workgroup start times (us): first round ends {starts[min(255, nwg-1)]:.1f}, median {np.median(starts):.1f}, last {starts[-1]:.1f}; kernel {ms*1e3:.1f} us "
       f"-> {ms*1e3/rounds:.1f} us per round of 256")
 print(f"{os.environ.get('GT_LIB','G2T')} N={N} K={K} M={M}: {ms:.3f} ms = {2.0*M*N*K/ms/1e9:.0f} TFLOP/s (timing build)")
