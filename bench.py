@@ -82,7 +82,7 @@ def layer_call(fm, wl, l, meta, ns, fused=None):
                                           SCALE, True)
 
 
-def k1_ragged_variant(dev, layers=8):
+def k1_ragged_variant(dev, layers=61):
     """SURVEY section 8(d) variant of the headline workload: cfg2 with RAGGED lengths uniform in 2048..6144 (mean 4096): K1 only,
     `layers` layer caches captured in one hipGraph, HIP events on the launch stream -> us per launch + achieved algorithmic GB/s."""
     import flash_mla_fp8 as fm

@@ -20,8 +20,8 @@
 //     buffered P' / references + wave-private scale scratch.  Rope (bf16, 4 KiB per QK wave and page) and the raw
 //     k_scale go global -> registers in the QK waves, two pages ahead (a rope ring does not fit beside the P buffers).
 //   * ONE s_barrier per page step: step i = QK(i) + softmax(i) || PV(i-1) + refill of page i+2.
-// Split requests (fewer requests than parts) write normalised bf16 partial rows + {weight-LSE, exact-LSE} exactly like
-// mla_decode_fp8_x.hip and are merged by mla_combine_kernel.
+// Split requests write normalised bf16 partial rows + {weight-LSE, exact-LSE}; with at least half as many requests as parts
+// the request's FIRST piece merges them inside this kernel (see the epilogue), otherwise mla_combine_kernel does.
 #include "mla_decode_shared.h"
 
 using namespace fl_mla;
@@ -38,11 +38,11 @@ constexpr int kOffScratch = kOffRef + 2 * kRefPerParity;           // [QK wave 4
 constexpr int kOffLm = kOffScratch + 4 * kScratchPerWave;          // [rt 2][W 2][3][32] f32: l, lq, m per row
 constexpr int kOffFlag = kOffLm + 2 * 2 * 3 * 32 * 4;              // 4 ints: redo votes of the PV waves
 constexpr int kOffQr = kOffFlag + 16;                                 // [QK wave 4][4 k-steps][64 lanes] 16 B: Q rope fragments
-constexpr int kOffMerge = kOffQr + 4 * 4096;                            // 2 ints: PV-wave arrivals, merge verdict (in-kernel split merge)
+constexpr int kOffMerge = kOffQr + 4 * 4096;                            // 1 int: PV waves of this workgroup past a merge's poll (in-kernel split merge)
 constexpr int kLdsBytes = kOffMerge + 16;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
-constexpr int kStgStride = 128 + 4;                                // epilogue staging: floats per row (in the ring)
-static_assert(4 * 32 * kStgStride * 4 <= kRingSlots * kSlotBytes, "epilogue staging fits the ring");
+constexpr int kStgBytes = 512 + 16;                                // epilogue staging: bytes per row (256 bf16 dims of a PV wave + pad; in the ring)
+static_assert(4 * 32 * kStgBytes <= kRingSlots * kSlotBytes, "epilogue staging fits the ring");
 
 constexpr int kPiecesPerWave = kDmaNopePerTile / 4;                // 8 LDS-DMA pieces of 1 KiB per PV wave and page
 
@@ -834,12 +834,17 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     lc.dn_x = (unsigned)((li ^ lh) << 4);
   }
   int* msync = reinterpret_cast<int*>(smem + kOffMerge);
-  if (wave_id == 4 && lane == 0) { msync[0] = 0; msync[1] = 0; }   // (first read behind the first request's barriers)
-  int frag_seq = 1;   // split fragments this workgroup has finished + 1 (identical in its four PV waves)
-  for (; req < p.bs; ++req, tile_b = 0, split_idx = 0) {
+  if (wave_id == 4 && lane == 0) msync[0] = 0;   // (first use behind the first request's barriers)
+  // "my partial rows of a split request are in memory" signal of this wave, owed to the request's merging piece: sent behind the
+  // NEXT s_waitcnt vmcnt(0) the wave executes anyway (the next request's R0, or the end of the workgroup)
+  int* pend_ctr = nullptr;
+  int pend_add = 0;
+  bool first_item = true;
+  for (; req < p.bs; ++req, tile_b = 0, split_idx = 0, first_item = false) {
     FL_Y_REQUEST_HEAD();
     const int split_base = g_num_splits[req];
-    const bool is_split = (g_num_splits[req + 1] - split_base) > 1;
+    const int nsplit = g_num_splits[req + 1] - split_base;
+    const bool is_split = nsplit > 1;
     auto ring = [&](int t) { return smem + kOffRing + (t & 3) * kSlotBytes; };
     auto src_of = [&](int t) { return g_k_nope + page_of(t) * (long long)(kPage * (FMT == 1 ? kDN + kDR : kDN)); };
     auto issue_page = [&](int t) {
@@ -864,10 +869,22 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       int redo = 0;
       if (pass == 1) load_window(0);
 
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // R0
-      if (n > 0) issue_page(0);
-      if (n > 1) issue_page(1);
+      if (first_item && pass == 0) {
+        // the workgroup's first request: nobody has touched the ring yet — the first two pages go out as soon as their ids are
+        // here, not behind the QK waves' rope / scale loads (R0): one memory round trip less in the start-up chain
+        if (n > 0) issue_page(0);
+        if (n > 1) issue_page(1);
+        __builtin_amdgcn_s_barrier();   // R0
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (pend_ctr != nullptr) {   // (the partial rows of the previous request have been acknowledged)
+          if (lane == 0) __hip_atomic_fetch_add(pend_ctr, pend_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pend_ctr = nullptr;
+        }
+        __builtin_amdgcn_s_barrier();   // R0
+        if (n > 0) issue_page(0);
+        if (n > 1) issue_page(1);
+      }
       FL_T(5);   // request prologue
 
       // step i: wait for page i, barrier B_i, PV(i-1) with the refill of page i+2 in its MFMA shadow, tail fill of page i.
@@ -935,135 +952,235 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     // split-KV partials are normalised by lq, so they are COMBINED with lq-based weights; the exact LSE travels along
     const float lseq_nat = lq > 0.f ? (__builtin_amdgcn_logf(lq) + m_o - kPShift) * 0.6931471805599453f : -INFINITY;
     const int slot_idx = split_base + split_idx;
+    // In-kernel split merge (no second kernel): the request's FIRST piece merges.  The pieces of a request lie in consecutive
+    // parts, the first piece is the LAST item of its part and every other piece is the first (or only) item of a later part, so
+    // the merging piece normally finishes last; it keeps its own rows in registers / LDS (they never travel through memory),
+    // waits until the other pieces' PV waves have signalled (4 per piece on the (request, row group) counter in the spare
+    // metadata columns of the merging part: 16 bits per row group, K3 zeroes them, the merging workgroup puts them back), reads
+    // their bf16 rows and writes the final rows.  A waiting piece never waits for a piece that itself waits (only LAST items
+    // wait, only on FIRST / only items of later parts), so any dispatch order makes progress.
+    // Hand-off form (MI355X guide, "handoff-flag": write-through payload -> drained vmcnt -> counter -> sc1 loads): partial
+    // rows / LSE pairs are stored with the agent-scope policy (sc1 = write-through past this XCD's non-coherent L2) and read
+    // back with sc1 loads, served by the memory side — no cache-wide write-back / invalidate on either side (validated in
+    // rounds 2-3: tools/determinism_ragged.py).  The arithmetic is combine_rows16's / the merge kernel's, piece by piece in order.
+    const bool merger = is_split && p.merge_in_kernel && split_idx == 0;
     if (row_ok && lh == 0 && W == 0) {
       // (the row index is made opaque HERE: derived 64-bit offsets — row / h_q, the LSE slots — are otherwise formed before the page
       //  loop and spilled across it)
       unsigned row_e = (unsigned)row;
       asm volatile("" : "+v"(row_e));
-      if (is_split) {   // (agent-scope stores: read by whichever part merges the request, see the merge below)
-        float* la = p.lse_accum + (long long)slot_idx * p.rows * 2;
-        st_agent_f32(la + row_e * 2u + 0, lseq_nat);
-        st_agent_f32(la + row_e * 2u + 1, lse_nat);
+      if (is_split) {
+        if (!merger) {   // (agent-scope stores: read by the merging piece / the merge kernel)
+          float* la = p.lse_accum + (long long)slot_idx * p.rows * 2;
+          st_agent_f32(la + row_e * 2u + 0, lseq_nat);
+          st_agent_f32(la + row_e * 2u + 1, lse_nat);
+        }
       } else {
         const unsigned j = row_e / (unsigned)p.h_q, h = row_e - j * (unsigned)p.h_q;
         p.lse[((long long)req * p.h_q + h) * p.s_q + j] = lse_nat;
       }
     }
-    // O -> memory through a wave-private LDS transpose (the ring is free now).  A lane holds ONE row, 4 dims at a
-    // time: stored directly, every store instruction would touch 64 rows x 8 B.  Tiles 4c..4c+3 cover the contiguous
-    // dims [256W + 128c, +128) (C row i = e + 8g + 4lh of tile 4c + jq is d = 128c + 16jq + (i&15) + 64(i>>4)), so
-    // chunk c is staged as [32 rows][128 f32] (+4 pad) and leaves as 256-B bf16 row segments.
+    // O -> memory through a wave-private LDS transpose (the ring is free now).  A lane holds ONE row, 4 dims at a time:
+    // stored directly, every store instruction would touch 64 rows x 8 B.  C row i = e + 8g + 4lh of tile 4c + jq is
+    // d = 128c + 16jq + (i&15) + 64(i>>4) of the wave's 256 dims: the normalised values are rounded to bf16 (v_cvt_pk_bf16_f32,
+    // RNE) and staged as [32 rows][256 bf16] (+16 B pad), then leave as 256-B row segments, 4 rows per store instruction.
     {
-      float* stg = reinterpret_cast<float*>(smem + kOffRing) + w4 * (32 * kStgStride);
+      uint8_t* stg = smem + kOffRing + w4 * (32 * kStgBytes);
       const int row0 = rgrp * 64 + rt * 32;
-      uint16_t* dst = is_split ? reinterpret_cast<uint16_t*>(p.o_accum) + ((long long)slot_idx * p.rows + row0) * kDN
-                               : p.out + ((long long)req * p.rows + row0) * kDN;
-#ifndef FL_Y_EPI_SADDR
-#define FL_Y_EPI_SADDR 1   // the epilogue's 8 row addresses as ONE uniform base (SGPR pair, pinned behind the page loop) + 32-bit lane
-                           // offsets: hipcc otherwise forms eight 64-bit row pointers BEFORE the page loop (they depend on the request
-                           // only) and, with the PV wave at 256 registers, spills them — 14 scratch stores in the request prologue,
-                           // ~40 dependent scratch reloads in the epilogue (104 B of scratch per lane: VERDICT r2 item 3d)
-#endif
-#if FL_Y_EPI_SADDR
+      int* ctr = g_merge_ctr + (long long)part * FL_MLA_META_W + 5 + (rgrp >> 1);   // (merging piece: split_idx == 0)
+      // first look at the counter: issued here, used behind the staging (its round trip runs under the conversions)
+      int arrived = merger ? __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      uint16_t* dst = (is_split && !merger) ? reinterpret_cast<uint16_t*>(p.o_accum) + ((long long)slot_idx * p.rows + row0) * kDN
+                                            : p.out + ((long long)req * p.rows + row0) * kDN;
+      // the row addresses as ONE uniform base (SGPR pair, pinned behind the page loop) + 32-bit lane offsets: hipcc otherwise
+      // forms 64-bit row pointers BEFORE the page loop (they depend on the request only) and, with the PV wave at 256
+      // registers, spills them
       {
         unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)dst);
         unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)dst >> 32));
         asm volatile("" : "+s"(lo), "+s"(hi));   // (computed HERE, after the loop)
         dst = reinterpret_cast<uint16_t*>(((unsigned long long)hi << 32) | lo);
       }
-#endif
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int jq = 0; jq < 4; ++jq)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int d_off = 16 * jq + 8 * (g & 1) + 4 * lh + 64 * (g >> 1);
-            *reinterpret_cast<float4*>(stg + li * kStgStride + d_off) =
-                make_float4(o[4 * c + jq][g * 4 + 0] * inv, o[4 * c + jq][g * 4 + 1] * inv,
-                            o[4 * c + jq][g * 4 + 2] * inv, o[4 * c + jq][g * 4 + 3] * inv);
+            const int d_off = 128 * c + 16 * jq + 8 * (g & 1) + 4 * lh + 64 * (g >> 1);
+            *reinterpret_cast<uint2*>(stg + li * kStgBytes + 2 * d_off) =
+                make_uint2(fl_pack_bf16(o[4 * c + jq][g * 4 + 0] * inv, o[4 * c + jq][g * 4 + 1] * inv),
+                           fl_pack_bf16(o[4 * c + jq][g * 4 + 2] * inv, o[4 * c + jq][g * 4 + 3] * inv));
           }
-#if FL_Y_EPI_SADDR
-        unsigned voff = (unsigned)(256 * W + 128 * c + (lane & 15) * 8 + (lane >> 4) * kDN);   // elements; row r = (lane >> 4) + 4 k: + 4 k kDN
-        asm volatile("" : "+v"(voff));
-#else
-        uint16_t* dbase = dst + 256 * W + 128 * c + (lane & 15) * 8;
-#endif
+      unsigned voff = (unsigned)(256 * W + (lane & 15) * 8 + (lane >> 4) * kDN);   // elements; row r = (lane >> 4) + 4 k: + 4 k kDN; half c: + 128
+      asm volatile("" : "+v"(voff));
+      const uint8_t* rd = stg + (lane >> 4) * kStgBytes + (lane & 15) * 16;          // + 4 k kStgBytes + 256 c
+      if (!merger) {
+        // all sixteen row segments come back from LDS before the first store: left to itself hipcc sinks each read under its
+        // store's row predicate (read -> wait -> store, sixteen times in series)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 ov[2][8];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ov[c][k] = *reinterpret_cast<const u32x4*>(rd + 4 * k * kStgBytes + 256 * c);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          asm volatile("" : "+v"(ov[c][0]), "+v"(ov[c][1]), "+v"(ov[c][2]), "+v"(ov[c][3]), "+v"(ov[c][4]), "+v"(ov[c][5]), "+v"(ov[c][6]), "+v"(ov[c][7]));
+        if (is_split) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              if (row0 + (lane >> 4) + 4 * k < p.rows)
+                st_agent_16B(dst + (voff + (unsigned)(4 * k * kDN + 128 * c)), make_uint4(ov[c][k][0], ov[c][k][1], ov[c][k][2], ov[c][k][3]));
+        } else {
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              if (row0 + (lane >> 4) + 4 * k < p.rows)
+                *reinterpret_cast<u32x4*>(dst + (voff + (unsigned)(4 * k * kDN + 128 * c))) = ov[c][k];
+        }
+        if (is_split && p.merge_in_kernel) {   // owed: one count per PV wave, behind the wave's next s_waitcnt vmcnt(0)
+          pend_ctr = g_merge_ctr + (long long)(part - split_idx) * FL_MLA_META_W + 5 + (rgrp >> 1);
+          pend_add = 1 << (16 * (rgrp & 1));
+        }
+      } else {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const int sh = 16 * (rgrp & 1);
+        const int tgt = 4 * (nsplit - 1);
+        FL_T(4);   // epilogue
+        while (((arrived >> sh) & 0xffff) != tgt) {
+          __builtin_amdgcn_s_sleep(2);
+          arrived = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        FL_T(7);   // merging piece: wait for the other pieces
+        if (lane == 0) {   // the last of the four PV waves past the poll puts the counter back (the same metadata serves every layer's launch)
+          const int old = __hip_atomic_fetch_add(msync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if ((old & 3) == 3) __hip_atomic_fetch_sub(ctr, tgt << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint16_t* parts = reinterpret_cast<const uint16_t*>(p.o_accum);
+        auto ld16 = [&](const uint16_t* src) {
+          const unsigned long long* q8 = reinterpret_cast<const unsigned long long*>(src);
+          const unsigned long long lo = __hip_atomic_load(q8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long hi = __hip_atomic_load(q8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+        };
+        // every load of the common case (2 pieces; up to 5 for the weights) goes out before the first use: ONE round trip
+        const long long rowg = row_ok ? row : p.rows - 1;   // this lane's own row (li), clamped: loads are unconditional
+        float a1[4], b1[4];   // {weight LSE, exact LSE} of pieces 1..4 for this lane's row (clamped duplicates beyond the last)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int sj = 1 + j < nsplit ? 1 + j : nsplit - 1;
+          const float* la = p.lse_accum + ((long long)(split_base + sj) * p.rows + rowg) * 2;
+          a1[j] = ld_agent_f32(la);
+          b1[j] = ld_agent_f32(la + 1);
+        }
+        // row r = (lane >> 4) + 4 k of the tile, 8 dims per lane: element offset of this lane's chunk inside a piece's rows
+        unsigned poff[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const int r = (lane >> 4) + 4 * k;
-          const float4 v0 = *reinterpret_cast<const float4*>(stg + r * kStgStride + (lane & 15) * 8);
-          const float4 v1 = *reinterpret_cast<const float4*>(stg + r * kStgStride + (lane & 15) * 8 + 4);
-          uint4 ov;   // v_cvt_pk_bf16_f32: RNE, two values per instruction
-          ov.x = fl_pack_bf16(v0.x, v0.y);
-          ov.y = fl_pack_bf16(v0.z, v0.w);
-          ov.z = fl_pack_bf16(v1.x, v1.y);
-          ov.w = fl_pack_bf16(v1.z, v1.w);
-          if (row0 + r < p.rows) {
-#if FL_Y_EPI_SADDR
-            uint16_t* ptr = dst + (voff + (unsigned)(4 * k * kDN));
-#else
-            uint16_t* ptr = dbase + (long long)r * kDN;
-#endif
-            if (is_split) st_agent_16B(ptr, ov);
-            else *reinterpret_cast<uint4*>(ptr) = ov;
+          const int rr = row0 + (lane >> 4) + 4 * k;
+          poff[k] = (unsigned)((rr < p.rows ? rr : p.rows - 1) * kDN + 256 * W + (lane & 15) * 8);
+        }
+        u32x4 ch[2][8];
+        {
+          const uint16_t* p1 = parts + (long long)(split_base + 1) * p.rows * kDN;
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ch[c][k] = ld16(p1 + poff[k] + 128 * c);
+        }
+        float mx = lseq_nat, mxx = lse_nat;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mx = fmaxf(mx, a1[j]); mxx = fmaxf(mxx, b1[j]); }
+        for (int s5 = 5; s5 < nsplit; ++s5) {
+          const float* la = p.lse_accum + ((long long)(split_base + s5) * p.rows + rowg) * 2;
+          mx = fmaxf(mx, ld_agent_f32(la));
+          mxx = fmaxf(mxx, ld_agent_f32(la + 1));
+        }
+        const float w0 = mx == -INFINITY ? 0.f : __expf(lseq_nat - mx);
+        float den = 0.f, denx = 0.f;
+        den += w0;
+        denx += mxx == -INFINITY ? 0.f : __expf(lse_nat - mxx);
+        float wj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool live = 1 + j < nsplit;
+          wj[j] = (!live || mx == -INFINITY) ? 0.f : __expf(a1[j] - mx);
+          den += wj[j];
+          denx += (!live || mxx == -INFINITY) ? 0.f : __expf(b1[j] - mxx);
+        }
+        for (int s5 = 5; s5 < nsplit; ++s5) {
+          const float* la = p.lse_accum + ((long long)(split_base + s5) * p.rows + rowg) * 2;
+          den += mx == -INFINITY ? 0.f : __expf(ld_agent_f32(la) - mx);
+          denx += mxx == -INFINITY ? 0.f : __expf(ld_agent_f32(la + 1) - mxx);
+        }
+        const float invd = den > 0.f ? 1.f / den : 0.f;
+        if (row_ok && lh == 0 && W == 0) {
+          const unsigned j = (unsigned)row / (unsigned)p.h_q, h = (unsigned)row - j * (unsigned)p.h_q;
+          p.lse[((long long)req * p.h_q + h) * p.s_q + j] = denx > 0.f ? mxx + __logf(denx) : -INFINITY;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float acc[8][8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int r = (lane >> 4) + 4 * k;
+            const uint4 own = *reinterpret_cast<const uint4*>(rd + 4 * k * kStgBytes + 256 * c);
+            const uint32_t ow[4] = {own.x, own.y, own.z, own.w};
+            const float w0r = __shfl(w0, r), w1r = __shfl(wj[0], r);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+              acc[k][2 * h] = 0.f;
+              acc[k][2 * h + 1] = 0.f;
+              acc[k][2 * h] += w0r * __uint_as_float(ow[h] << 16);
+              acc[k][2 * h + 1] += w0r * __uint_as_float(ow[h] & 0xffff0000u);
+              acc[k][2 * h] += w1r * __uint_as_float(ch[c][k][h] << 16);
+              acc[k][2 * h + 1] += w1r * __uint_as_float(ch[c][k][h] & 0xffff0000u);
+            }
+          }
+          for (int s2 = 2; s2 < nsplit; ++s2) {   // third and later pieces: one round trip per (piece, half)
+            float ws = s2 == 2 ? wj[1] : s2 == 3 ? wj[2] : wj[3];
+            if (s2 > 4) {
+              const float v = ld_agent_f32(p.lse_accum + ((long long)(split_base + s2) * p.rows + rowg) * 2);
+              ws = mx == -INFINITY ? 0.f : __expf(v - mx);
+            }
+            const uint16_t* ps = parts + (long long)(split_base + s2) * p.rows * kDN;
+            u32x4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = ld16(ps + poff[k] + 128 * c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float wr = __shfl(ws, (lane >> 4) + 4 * k);
+#pragma unroll
+              for (int h = 0; h < 4; ++h) {
+                acc[k][2 * h] += wr * __uint_as_float(t[k][h] << 16);
+                acc[k][2 * h + 1] += wr * __uint_as_float(t[k][h] & 0xffff0000u);
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int r = (lane >> 4) + 4 * k;
+            const float ir = __shfl(invd, r);
+            if (row0 + r < p.rows)
+              *reinterpret_cast<uint4*>(dst + (voff + (unsigned)(4 * k * kDN + 128 * c))) =
+                  make_uint4(fl_pack_bf16(acc[k][0] * ir, acc[k][1] * ir), fl_pack_bf16(acc[k][2] * ir, acc[k][3] * ir),
+                             fl_pack_bf16(acc[k][4] * ir, acc[k][5] * ir), fl_pack_bf16(acc[k][6] * ir, acc[k][7] * ir));
           }
         }
-      }
-    }
-    // ---- split-KV merge WITHOUT a second kernel: the part that finishes a (request, row group) LAST merges it.  Every PV
-    //      wave waits for its partial stores, the fourth one of the workgroup bumps the (request, row group) counter in the
-    //      spare metadata columns of the request's first part (16 bits per row group; K3 zeroes them, the merging part
-    //      puts them back to zero: the same metadata serves every layer's launch), and tells its three siblings through
-    //      LDS whether this workgroup is the last.  The last one reads the other parts' partials (agent-scope loads of
-    //      agent-scope stores: no cache-wide fence) and writes the final rows, 16 rows per PV wave (combine_rows16). ----
-    if (is_split && p.merge_in_kernel) {
-      // Hand-off form (MI355X guide, "handoff-flag": write-through payload -> drained vmcnt -> counter -> sc1 loads):
-      //   * every partial row / LSE pair above was stored with the agent-scope policy (sc1 = write-through past this
-      //     XCD's non-coherent L2: st_agent_16B / st_agent_f32), and the merging part reads them back with sc1 loads
-      //     (combine_rows16: agent-scope relaxed atomic loads), which are served by the memory side, never by a stale
-      //     L1 / L2 line — so no cache-wide write-back or invalidate is needed on either side;
-      //   * the wave drains its own stores here (inline asm: a wait hipcc cannot drop) BEFORE it is counted as arrived
-      //     in LDS; the fourth arriver bumps the request's agent-scope counter only after all four waves have drained.
-      // (Round 2 shipped this code with an agent RELEASE fence behind an #ifdef that no build defined, next to a comment
-      //  saying the wait alone had not been enough — that observation predates the write-through stores.  The form that
-      //  has actually been validated, in round 2 and again in round 3, is this fence-less one: tools/determinism_ragged.py,
-      //  profiles/r03_determinism_ragged_inkernel_merge.txt.  A per-fragment buffer_wbl2 would also be correct but
-      //  writes back the XCD's whole L2 under the other workgroups' page streams.)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      int verdict = 0;
-      if (lane == 0) {
-        const int old = __hip_atomic_fetch_add(msync, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((old & 3) == 3) {
-          const int nsplit = g_num_splits[req + 1] - split_base;
-          int* ctr = g_merge_ctr + (long long)(part - split_idx) * FL_MLA_META_W + 5 + (rgrp >> 1);
-          const int sh = 16 * (rgrp & 1);
-          const int g_old = (atomicAdd(ctr, 1 << sh) >> sh) & 0xffff;
-          int st = 1;
-          if (g_old == nsplit - 1) {
-            st = 2;
-            atomicSub(ctr, nsplit << sh);
-          }
-          __hip_atomic_store(msync + 1, (frag_seq << 2) | st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        while (((verdict = __hip_atomic_load(msync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 2) != frag_seq)
-          __builtin_amdgcn_s_sleep(1);
-      }
-      verdict = __builtin_amdgcn_readfirstlane(verdict);
-      ++frag_seq;
-      if ((verdict & 3) == 2) {
-        const int nsplit = g_num_splits[req + 1] - split_base;
-        const int rb = rgrp * 64 + w4 * 16;
-        if (rb < p.rows) {
-          if (nsplit == 2) combine_rows16<2>(p, req, rb, split_base, nsplit, lane);
-          else if (nsplit == 3) combine_rows16<3>(p, req, rb, split_base, nsplit, lane);
-          else combine_rows16<0>(p, req, rb, split_base, nsplit, lane);
-        }
+        FL_T(8);   // merging piece: read the other pieces, combine, store
       }
     }
     FL_T(4);   // epilogue
   }
 #undef FL_Y_REQUEST_HEAD
+  if (pend_ctr != nullptr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(pend_ctr, pend_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #ifdef FL_MLA_TIMING
   if (g_dbg_y != nullptr && lane == 0) {
     unsigned long long* d = reinterpret_cast<unsigned long long*>(g_dbg_y) + ((long long)blockIdx.x * 8 + wave_id) * 14;
@@ -1103,7 +1220,7 @@ int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipSt
       p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, const_cast<int32_t*>(a->tile_scheduler_metadata), a->num_splits,
       (const uint8_t*)a->k_nope, (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
   FL_CHECK_LAUNCH("mla_decode_y_kernel");
-  // split requests are merged inside the kernel by their last-arriving part (six 16-bit counters per part: up to 6 row
+  // split requests are merged inside the kernel by their first piece (six 16-bit arrival counters per part: up to 6 row
   // groups); beyond that, or with FLUENT_MLA_MERGE_KERNEL=1, the separate merge kernel runs
   return p.merge_in_kernel ? FL_OK : fl_mla_launch_combine(p, a->num_splits, stream);
 }

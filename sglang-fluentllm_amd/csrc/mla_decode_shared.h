@@ -32,7 +32,7 @@ struct Params {
   float* o_accum;
   float* lse_accum;
   int partial_bf16;   // o_accum holds bf16 rows (128-row mapping) instead of f32 rows
-  int merge_in_kernel;   // mla_decode_fp8_y.hip: split requests are merged by their last-arriving part (no merge kernel)
+  int merge_in_kernel;   // mla_decode_fp8_y.hip: split requests are merged by their first piece (no merge kernel)
   const uint16_t* q_bf16;   // mla_decode_fp8_y.hip <0, true>: unquantised query rows [bs * rows, 576] (K4 in the prologue)
 };
 

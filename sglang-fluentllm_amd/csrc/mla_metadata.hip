@@ -9,12 +9,12 @@
 // everything (searched over [ceil(total/num_parts), +63], one candidate per lane), so that e.g. 128 equal requests on
 // 256 parts split 32/32 pages instead of 33/31 (the fixed formula ceil(total/parts) + FIXED_OVERHEAD lets the first
 // part of every request run ahead: the kernel ends with its slowest workgroup).  m[5] of every part is zeroed: it is
-// the "partial ready" flag of the in-kernel split merge (mla_decode_fp8_x.hip), set and reset by the decode kernel.
+// the arrival counters of the in-kernel split merge (mla_decode_fp8_y.hip), bumped and put back by the decode kernel.
 // Python statement of the same algorithm: oracle/mla_ref.py:get_mla_metadata.
 #include "fl_common.h"
 
 namespace {
-constexpr int kFixedOverhead = 2;
+constexpr int kFixedOverhead = 2;   // (round 4: 4 / 6 / 8 measured on the ragged cfg2 workload and bs = 16..96: within 1 % of 2)
 constexpr int kMinSplitCap = 32, kPagesPerSplit = 8;   // parts per request <= max(32, pages / 8) (oracle/mla_ref.py)
 constexpr int kMaxBs = 8192;   // tile counts are staged in LDS
 

@@ -825,8 +825,9 @@ def test_replay_reference_call_trace(fm):
 
 
 def test_split_merge_inside_the_decode_kernel_on_every_split_case():
-    """The role-specialised mapping merges split requests INSIDE the decode kernel (last-arriving part, mla_decode_fp8_y.hip)
-    when there are at least as many requests as parts; smaller batches take the merge kernel.  Here the parity cases, the
+    """The role-specialised mapping merges split requests INSIDE the decode kernel (the request's first piece waits for the
+    others' arrival counts and merges from its registers, mla_decode_fp8_y.hip) when there are at least half as many requests
+    as parts; smaller batches take the merge kernel.  Here the parity cases, the
     reference-jump cases and the graph-replay test of this file run once more in a process that forces the in-kernel merge
     for every shape (FLUENT_MLA_MERGE_KERNEL=0 is read once per process), so that its counters (spare metadata columns,
     reset by the merging part), the many-way splits (ns up to 128) and replays on unchanged metadata are all exercised."""

@@ -4,6 +4,6 @@
 R=$1; shift
 for i in $(seq $R); do
   for L in "$@"; do
-    FLUENT_MI355_LIB=$PWD/sglang-fluentllm_amd/fluent_mi355/$L FLUENT_MLA_LIB_TAG=$L python tools/time_k1.py ${H:-128} ${BS:-128} ${SEQ:-4096} 2>/dev/null | tail -1
+    FLUENT_MI355_LIB=$PWD/sglang-fluentllm_amd/fluent_mi355/$L FLUENT_MLA_LIB_TAG=$L LAYERS=${LAYERS:-61} python tools/time_k1.py ${H:-128} ${BS:-128} ${SEQ:-4096} 2>/dev/null | tail -1
   done
 done

@@ -8,7 +8,7 @@ import flash_mla_fp8 as fm
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 res = {}
-for bs, seq, H in ((1, 128, 16), (2, 129, 16), (1, 64, 128), (3, 200, 64), (1, 9000, 128), (3, 2000, 64), (5, 3000, 128)):   # the last three: split requests, merged in-kernel by their last-arriving part — the SAME metadata (merge counters) serves every launch
+for bs, seq, H in ((1, 128, 16), (2, 129, 16), (1, 64, 128), (3, 200, 64), (1, 9000, 128), (3, 2000, 64), (5, 3000, 128)):   # the last three: split requests, merged in-kernel by their first piece — the SAME metadata (merge counters) serves every launch
     wl = bench.build_workload(dev, 1, bs, seq, H, seed=bs + seq)
     meta, ns = fm.get_mla_metadata(wl["seqlens"], H, 1)
     qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)

@@ -1,5 +1,5 @@
 """GPU box: the ragged cfg2 workload (128 requests, lengths 2048..6144, H=128: ~122 requests split in two and merged INSIDE
-the decode kernel by their last-arriving part) launched many times on the same metadata; every output is compared bit for
+the decode kernel by their first piece, which waits for the arrival counts of the others) launched many times on the same metadata; every output is compared bit for
 bit with the first.  A merge that read a partial row too early, a counter that was not put back to zero, or a lost
 arrival would show as a mismatch (or a hang: run under `timeout`).  usage: tools/determinism_ragged.py [iterations]"""
 import json, os, sys

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sglang-fluentllm_amd"))
 import torch, bench
 import flash_mla_fp8 as fm
-layers = 8
+layers = int(os.environ.get("LAYERS", "8"))
 H = int(sys.argv[1]) if len(sys.argv) > 1 else bench.H
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else bench.BS
 seq = int(sys.argv[3]) if len(sys.argv) > 3 else bench.SEQ
