@@ -9,7 +9,7 @@ import torch, numpy as np
 import deep_gemm
 from fluent_mi355._lib import lib
 dev = torch.device("cuda:0")
-E, N, K, R = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 4096, int(sys.argv[2]) if len(sys.argv) > 2 else 7168, int(os.environ.get("GT_ROWS", "512"))
+E, N, K, R = int(os.environ.get("GT_E", "32")), int(sys.argv[1]) if len(sys.argv) > 1 else 4096, int(sys.argv[2]) if len(sys.argv) > 2 else 7168, int(os.environ.get("GT_ROWS", "512"))
 g = torch.Generator(device=dev).manual_seed(0)
 W = torch.randint(0, 120, (E, N, K), device=dev, generator=g, dtype=torch.uint8).view(torch.float8_e4m3fn)
 Ws = torch.rand(E, N // 128, K // 128, device=dev, generator=g) * 1e-2
