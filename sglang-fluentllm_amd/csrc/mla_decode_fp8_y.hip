@@ -1012,9 +1012,13 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
                 make_uint2(fl_pack_bf16(o[4 * c + jq][g * 4 + 0] * inv, o[4 * c + jq][g * 4 + 1] * inv),
                            fl_pack_bf16(o[4 * c + jq][g * 4 + 2] * inv, o[4 * c + jq][g * 4 + 3] * inv));
           }
-      unsigned voff = (unsigned)(256 * W + (lane & 15) * 8 + (lane >> 4) * kDN);   // elements; row r = (lane >> 4) + 4 k: + 4 k kDN; half c: + 128
+      // (the lane index is made opaque HERE: everything derived from it below — row numbers, row predicates, the pieces' offsets — would
+      //  otherwise be formed before the page loop, they depend on the request only, and spilled across it)
+      int lane_q = lane;
+      asm volatile("" : "+v"(lane_q));
+      unsigned voff = (unsigned)(256 * W + (lane_q & 15) * 8 + (lane_q >> 4) * kDN);   // elements; row r = (lane >> 4) + 4 k: + 4 k kDN; half c: + 128
       asm volatile("" : "+v"(voff));
-      const uint8_t* rd = stg + (lane >> 4) * kStgBytes + (lane & 15) * 16;          // + 4 k kStgBytes + 256 c
+      const uint8_t* rd = stg + (lane_q >> 4) * kStgBytes + (lane_q & 15) * 16;          // + 4 k kStgBytes + 256 c
       if (!merger) {
         // all sixteen row segments come back from LDS before the first store: left to itself hipcc sinks each read under its
         // store's row predicate (read -> wait -> store, sixteen times in series)
@@ -1032,14 +1036,14 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-              if (row0 + (lane >> 4) + 4 * k < p.rows)
+              if (row0 + (lane_q >> 4) + 4 * k < p.rows)
                 st_agent_16B(dst + (voff + (unsigned)(4 * k * kDN + 128 * c)), make_uint4(ov[c][k][0], ov[c][k][1], ov[c][k][2], ov[c][k][3]));
         } else {
 #pragma unroll
           for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-              if (row0 + (lane >> 4) + 4 * k < p.rows)
+              if (row0 + (lane_q >> 4) + 4 * k < p.rows)
                 *reinterpret_cast<u32x4*>(dst + (voff + (unsigned)(4 * k * kDN + 128 * c))) = ov[c][k];
         }
         if (is_split && p.merge_in_kernel) {   // owed: one count per PV wave, behind the wave's next s_waitcnt vmcnt(0)
@@ -1081,8 +1085,8 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
         unsigned poff[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const int rr = row0 + (lane >> 4) + 4 * k;
-          poff[k] = (unsigned)((rr < p.rows ? rr : p.rows - 1) * kDN + 256 * W + (lane & 15) * 8);
+          const int rr = row0 + (lane_q >> 4) + 4 * k;
+          poff[k] = (unsigned)((rr < p.rows ? rr : p.rows - 1) * kDN + 256 * W + (lane_q & 15) * 8);
         }
         u32x4 ch[2][8];
         {
@@ -1127,7 +1131,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           float acc[8][8];
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const int r = (lane >> 4) + 4 * k;
+            const int r = (lane_q >> 4) + 4 * k;
             const uint4 own = *reinterpret_cast<const uint4*>(rd + 4 * k * kStgBytes + 256 * c);
             const uint32_t ow[4] = {own.x, own.y, own.z, own.w};
             const float w0r = __shfl(w0, r), w1r = __shfl(wj[0], r);
@@ -1153,7 +1157,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
             for (int k = 0; k < 8; ++k) t[k] = ld16(ps + poff[k] + 128 * c);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              const float wr = __shfl(ws, (lane >> 4) + 4 * k);
+              const float wr = __shfl(ws, (lane_q >> 4) + 4 * k);
 #pragma unroll
               for (int h = 0; h < 4; ++h) {
                 acc[k][2 * h] += wr * __uint_as_float(t[k][h] << 16);
@@ -1163,7 +1167,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           }
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const int r = (lane >> 4) + 4 * k;
+            const int r = (lane_q >> 4) + 4 * k;
             const float ir = __shfl(invd, r);
             if (row0 + r < p.rows)
               *reinterpret_cast<uint4*>(dst + (voff + (unsigned)(4 * k * kDN + 128 * c))) =
