@@ -417,15 +417,19 @@ def dense_roofline(dev, T=256):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / (reps * copies)
 
-    for N, K in ((2176, 7168), (7168, 2048)):
+    # `frac_of_floor` = max(weight bytes / 8 TB/s, flops / 5 PFLOP/s) / measured: the binding roof of the two
+    for N, K, Ts in ((2176, 7168, (T, 32)), (7168, 2048, (T, 32)), (14336, 7168, (T, 32))):
         Ws = [(torch.randint(0, 120, (N, K), device=dev, generator=g, dtype=torch.uint8).view(torch.float8_e4m3fn),
                torch.rand((N + 127) // 128, K // 128, device=dev, generator=g) * 1e-2) for _ in range(8)]
-        x = torch.randn(T, K, device=dev, generator=g).to(torch.bfloat16)
-        xq, xs = per_token_group_quant_fp8(x, column_major_scales=True)
-        out = torch.empty(T, N, dtype=torch.bfloat16, device=dev)
-        t = graph_time(lambda c: deep_gemm.gemm_fp8_fp8_bf16_nt((xq, xs), Ws[c], out), 8)
-        res[f"fp8_{N}x{K}"] = {"us": round(t * 1e6, 1), "weight_GBs": round(N * K / t / 1e9, 1),
-                               "hbm_frac": round(N * K / t / 1e9 / HBM_PEAK_GBS, 3), "TFLOPs": round(2.0 * T * N * K / t / 1e12, 1)}
+        for Tt in Ts:
+            x = torch.randn(Tt, K, device=dev, generator=g).to(torch.bfloat16)
+            xq, xs = per_token_group_quant_fp8(x, column_major_scales=True)
+            out = torch.empty(Tt, N, dtype=torch.bfloat16, device=dev)
+            t = graph_time(lambda c: deep_gemm.gemm_fp8_fp8_bf16_nt((xq, xs), Ws[c], out), 8)
+            floor = max(N * K / (HBM_PEAK_GBS * 1e9), 2.0 * Tt * N * K / 5e15)
+            res[f"fp8_{N}x{K}" + ("" if Tt == T else f"_T{Tt}")] = {
+                "us": round(t * 1e6, 1), "weight_GBs": round(N * K / t / 1e9, 1), "hbm_frac": round(N * K / t / 1e9 / HBM_PEAK_GBS, 3),
+                "TFLOPs": round(2.0 * Tt * N * K / t / 1e12, 1), "floor_us": round(floor * 1e6, 2), "frac_of_floor": round(floor / t, 3)}
         del Ws
     Hh = 128
     q = torch.randn(T, Hh, 192, device=dev, generator=g).to(torch.bfloat16)
