@@ -28,4 +28,5 @@ def run(T, N, K, reps=20, copies=8):
     us = e0.elapsed_time(e1) * 1e3 / (reps * copies)
     print(json.dumps({"T": T, "N": N, "K": K, "us": round(us, 1), "weight_GBs": round(N * K / us / 1e3, 1), "hbm_frac": round(N * K / us / 1e3 / 8000, 3)}))
 for T in (int(a) for a in (sys.argv[1:] or ["128", "256"])):
+    run(T, 7168, 16384)
     run(T, 2176, 7168); run(T, 3072, 1536); run(T, 7168, 2048); run(T, 7168 * 2, 7168)
