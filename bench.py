@@ -682,27 +682,44 @@ def main():
         budget = float(os.environ.get("FLUENT_BENCH_CFG4_TIMEOUT_S", "240"))
         line.update(_headline(tokens_per_s, world, a, ms_per_step, layers, graph_ok, roof, gemm, variants, cpu))
         torch.cuda.empty_cache()
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17),
-                   FLUENT_BENCH_CFG4="0")
         cmd = [sys.executable, os.path.abspath(__file__), "--mode", "cfg4", "--gpus", str(world), "--steps", str(max(3, min(a.steps, 10))),
                "--warmup", "2"]
-        try:
+        # Two attempts at most: the default routes first (decode-sized collectives and the EP exchange on the one-shot peer-mapped
+        # transport — never run across real GPUs by its builder), then, if any rank's child failed or hung, everything on RCCL
+        # (FLUENT_ONESHOT=0).  The ranks agree on the outcome with one all-reduce; the record names the route and the first failure.
+        first_error = None
+        for attempt, extra in enumerate(({}, {"FLUENT_ONESHOT": "0"})):
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", FLUENT_BENCH_CFG4="0",
+                       MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17 * (attempt + 1)), **extra)
+            ok, rec, err = 0, None, None
+            try:
+                if dist is not None:
+                    dist.barrier()
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=budget / 2)
+                for ln in reversed(r.stdout.strip().splitlines()):
+                    if ln.startswith("{"):
+                        rec = json.loads(ln)
+                        break
+                ok = 1 if r.returncode == 0 and (rank != 0 or rec is not None) else 0
+                if not ok:
+                    err = f"config-4 child exited with code {r.returncode}: {r.stderr.strip()[-300:]}"
+            except subprocess.TimeoutExpired:
+                err = f"config-4 child did not finish within {budget / 2:.0f} s (collectives inside the captured step)"
+            except Exception as ex:
+                err = f"{type(ex).__name__}: {ex}"[:300]
             if dist is not None:
-                dist.barrier()
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=budget)
-            rec = None
-            for ln in reversed(r.stdout.strip().splitlines()):
-                if ln.startswith("{"):
-                    rec = json.loads(ln)
-                    break
-            if rec is not None:
-                cfg4 = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "ms_per_layer", "scaling", "config") if k in rec}
-            elif rank == 0:
-                cfg4 = {"error": f"config-4 child exited with code {r.returncode}: {r.stderr.strip()[-300:]}"}
-        except subprocess.TimeoutExpired:
-            cfg4 = {"error": f"config-4 phase did not finish within {budget:.0f} s (collectives inside the captured step); DP record only"}
-        except Exception as ex:
-            cfg4 = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if ok:
+                if rec is not None:
+                    cfg4 = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "ms_per_layer", "scaling", "config") if k in rec}
+                    cfg4["attempt"] = "default routes (one-shot transport where it applies)" if attempt == 0 else "FLUENT_ONESHOT=0 (RCCL only)"
+                    if first_error:
+                        cfg4["first_attempt_error"] = first_error
+                break
+            first_error = first_error or err or "a peer rank's child failed"
+            cfg4 = {"error": first_error + ("" if attempt == 0 else " | RCCL-only attempt: " + (err or "a peer rank's child failed")) + "; DP record only"}
     if not line:
         line.update(_headline(tokens_per_s, world, a, ms_per_step, layers, graph_ok, roof, gemm, variants, cpu))
     emit()
