@@ -36,12 +36,31 @@ def run():
 o0, l0 = run(); o0, l0 = o0.clone(), l0.clone()
 bad = 0
 side = torch.cuda.Stream()
+# BESIDE_GEMM=1: a compute-regime grouped GEMM (256 x 256 tiles, one 8-wave workgroup per CU, ~5 ms) runs on the second stream the whole time, so
+# that the decode kernel's workgroups are dispatched late, out of step and onto whatever CUs come free: the merging piece of a split request
+# then really waits for pieces whose workgroups have not started (forward progress of the in-kernel split merge under CU contention)
+gemm = None
+if os.environ.get("BESIDE_GEMM") == "1":
+    import deep_gemm
+    E, R, Nn, K = 32, 2048, 4096, 7168
+    W = torch.randint(0, 120, (E, Nn, K), device=dev, generator=g, dtype=torch.uint8).view(torch.float8_e4m3fn)
+    Ws = torch.rand(E, Nn // 128, K // 128, device=dev, generator=g) * 1e-2
+    A = torch.randint(0, 120, (E * R, K), device=dev, generator=g, dtype=torch.uint8).view(torch.float8_e4m3fn)
+    As = torch.rand(E * R, K // 128, device=dev, generator=g)
+    ex = (torch.arange(E + 1, device=dev) * R).to(torch.int32)
+    gout = torch.empty(E * R, Nn, dtype=torch.bfloat16, device=dev)
+    gemm = lambda: deep_gemm.m_grouped_gemm_fp8_fp8_bf16_nt_offset((A, As), (W, Ws), gout, ex, use_pdl=True)
+    gemm(); torch.cuda.synchronize()
 for i in range(N):
-    if i % 5 == 0:   # disturb timing: competing traffic on another stream
+    if gemm is not None:
+        if i % 8 == 0:
+            with torch.cuda.stream(side):
+                gemm()
+    elif i % 5 == 0:   # disturb timing: competing traffic on another stream
         with torch.cuda.stream(side):
             torch.empty(1 << 26, device=dev).fill_(1.0)
     o1, l1 = run()
     bad += int(not (torch.equal(o1.view(torch.int16), o0.view(torch.int16)) and torch.equal(l1, l0)))
 torch.cuda.synchronize()
-print(json.dumps({"iterations": N, "split_requests": int(ns[-1]) - BS, "mismatching_launches": bad,
+print(json.dumps({"beside_gemm": gemm is not None, "iterations": N, "split_requests": int(ns[-1]) - BS, "mismatching_launches": bad,
                   "merge_counters_back_to_zero": bool((meta[:, 5:] == 0).all())}))
