@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256, 1) void dma_rate(const char* __restrict__ src,
       p += 4;
       if (p >= pieces) p -= pieces;
     }
-    if (DEPTH >= 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (DEPTH >= 32) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (DEPTH >= 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (DEPTH >= 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   }
@@ -107,6 +108,12 @@ int main() {
   run<8>(d, 16 << 20, 256, "HBM stream 16MB/WG");
   run<16>(d, 16 << 20, 256, "HBM stream 16MB/WG");
   run<16>(d, 16 << 20, 128, "HBM stream 16MB/WG");
+  run<32>(d, 16 << 20, 128, "HBM stream 16MB/WG");
+  run<32>(d, 16 << 20, 256, "HBM stream 16MB/WG");
+  run<8>(d, 16 << 20, 128, "HBM stream 16MB/WG");
+  run<4>(d, 16 << 20, 128, "HBM stream 16MB/WG");
+  run<16>(d, 16 << 20, 64, "HBM stream 16MB/WG");
+  run<32>(d, 16 << 20, 64, "HBM stream 16MB/WG");
   run<16, 1>(d, 16 << 20, 128, "HBM stream SWIZZLED");
   run<16, 1>(d, 16 << 20, 256, "HBM stream SWIZZLED");
   run<16, 1>(d, 64 << 10, 256, "L2-resident SWIZZLED");

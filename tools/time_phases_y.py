@@ -12,10 +12,14 @@ H = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else bench.BS
 seq = int(sys.argv[3]) if len(sys.argv) > 3 else bench.SEQ
 RAGGED = os.environ.get("RAGGED") == "1"   # lengths uniform in seq/2 .. 3 seq/2 (bench.py's cfg2_ragged at seq = 4096)
-wl = bench.build_workload(dev, 1, bs, seq * 3 // 2 if RAGGED else seq, H, seed=1)
+NL = int(os.environ.get("LAYERS", "1"))   # > 1: the launches walk NL distinct caches (HBM-cold pages: what the bench step sees)
+wl = bench.build_workload(dev, NL, bs, seq * 3 // 2 if RAGGED else seq, H, seed=1)
 if RAGGED:
     g = torch.Generator(device=dev).manual_seed(77)
     wl["seqlens"] = torch.randint(seq // 2, seq * 3 // 2 + 1, (bs,), device=dev, generator=g, dtype=torch.int32)
+if os.environ.get("SHARE_PAGES"):   # experiment: groups of k requests read the same pages (k = bs: every page an L2 hit after the first touch)
+    k_ = int(os.environ["SHARE_PAGES"])
+    wl["block_table"] = wl["block_table"][torch.arange(bs, device=dev) // k_ * k_].contiguous()
 meta, ns = fm.get_mla_metadata(wl["seqlens"], H, 1)
 qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
 pages = wl["pages"]
@@ -24,8 +28,8 @@ REC = 14
 dbg = torch.zeros(nblocks * 8 * REC * 2, dtype=torch.int32, device=dev)
 lib.fl_mla_debug_set_buffer_y.argtypes = [ctypes.c_void_p]
 lib.fl_mla_debug_set_buffer_y(dbg.data_ptr())
-k_lora, k_scale, k_rope = wl["caches"][0]
-for _ in range(3):
+for it_ in range(3 * NL):
+    k_lora, k_scale, k_rope = wl["caches"][it_ % NL]
     fm.flash_mla_ckv_fp8_per_token(qn, qr, k_lora.view(pages, 64, 1, 512), k_rope.view(pages, 64, 1, 64), qs,
                                    k_scale.view(pages, 64, 1, 1), wl["block_table"], wl["seqlens"], 512, meta, ns, bench.SCALE, True)
 torch.cuda.synchronize()
