@@ -146,6 +146,92 @@ def k1_ragged_variant(dev, layers=61):
             "splits": int(ns[-1]) - BS}
 
 
+def kernel_variants(dev, n_caches=16, launches=64):
+    """The other decode kernels of the path at the cfg2 batch (bs=128, seq=4096), measured like the headline's K1 (one hipGraph of `launches`
+    launches cycling over `n_caches` distinct caches = 5.4 GB and more: nothing is re-served from the 256 MB Infinity Cache; HIP events on the
+    launch stream): cfg2_h16 = K1 for the TP8 shard (H=16, mla_decode_fp8_kernel<1>: BASELINE.md section 4 row 2), k2_fp8 / k2_bf16 =
+    flash_mla_with_kvcache over a plain fp8 / bf16 [.,576] cache (flashmla_backend.py:163-175,227-254)."""
+    import flash_mla_fp8 as fm
+    import flash_mla_swap as fsw
+
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(5)
+    npg = SEQ // 64
+    pages = BS * npg + 1
+    bt = (torch.randperm(pages - 1, device=dev, generator=g).to(torch.int32) + 1).view(BS, npg).contiguous()
+    lens = torch.full((BS,), SEQ, dtype=torch.int32, device=dev)
+
+    def timed(call):
+        for l in range(n_caches):
+            call(l)
+        torch.cuda.synchronize()
+        s2 = torch.cuda.Stream()
+        s2.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s2):
+            call(0)
+        torch.cuda.current_stream().wait_stream(s2)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for i in range(launches):
+                call(i % n_caches)
+        gr.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / (reps * launches)
+
+    def record(name, workload, t, alg, **extra):
+        out[name] = dict(workload=workload, us_per_launch=round(t * 1e6, 2), GBs=round(alg / t / 1e9, 1),
+                         hbm_frac=round(alg / t / 1e9 / HBM_PEAK_GBS, 4), algorithmic_bytes_per_launch=alg, **extra)
+
+    # ---- K1, TP8 shard: H = 16 (every rank of an attention-TP8 group runs this shape over the replicated latent cache) ----
+    try:
+        h = 16
+        wl = build_workload(dev, n_caches, BS, SEQ, h, seed=77)
+        meta, ns = fm.get_mla_metadata(wl["seqlens"], h, 1)
+        qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
+        pg = wl["pages"]
+
+        def k1(l):
+            k_lora, k_scale, k_rope = wl["caches"][l]
+            fm.flash_mla_ckv_fp8_per_token(qn, qr, k_lora.view(pg, 64, 1, 512), k_rope.view(pg, 64, 1, 64), qs, k_scale.view(pg, 64, 1, 1),
+                                           wl["block_table"], wl["seqlens"], 512, meta, ns, SCALE, True)
+        record("cfg2_h16", "cfg2 TP8 shard: bs=128 seq=4096 H=16, per-token fp8 KV, K1 only (+ its split combine)", timed(k1),
+               algorithmic_bytes(BS, SEQ, h, 1), kernel="mla_decode_fp8_kernel<1,0> + mla_combine_kernel", parts=int(meta.shape[0]),
+               splits=int(ns[-1]) - BS)
+        del wl
+    except Exception as ex_:
+        out["cfg2_h16"] = {"error": f"{type(ex_).__name__}: {ex_}"[:300]}
+    torch.cuda.empty_cache()
+    # ---- K2: flash_mla_with_kvcache over ONE [.,576] cache tensor ----
+    for name, dtype, mod, esz in (("k2_fp8", torch.float8_e4m3fn, fm, 1), ("k2_bf16", torch.bfloat16, fsw, 2)):
+        try:
+            # N(0,1) values (random BYTES would be fp8 values up to 448: scores of 1e6)
+            base = torch.randn(pages, 64, 1, 576, device=dev, generator=g)
+            caches = [torch.roll(base, 7 * l, 0).to(dtype) for l in range(n_caches)]
+            del base
+            q = torch.randn(BS, 1, H, 576, device=dev, generator=g).to(dtype)
+            one = torch.ones(1, device=dev)
+            meta, ns = mod.get_mla_metadata(lens, H, 1)
+            if dtype == torch.bfloat16:
+                call = lambda l: mod.flash_mla_with_kvcache(q, caches[l], bt, lens, 512, meta, ns, SCALE, True)   # noqa: E731
+            else:
+                call = lambda l: mod.flash_mla_with_kvcache(q, caches[l], bt, lens, 512, meta, ns, SCALE, True, one, one)   # noqa: E731
+            alg = BS * (SEQ * 576 * esz + H * 576 * esz + H * 1024 + 4 * npg)
+            record(name, f"cfg2 batch, {'plain fp8' if esz == 1 else 'bf16'} [.,576] cache: bs=128 seq=4096 H=128, flash_mla_with_kvcache", timed(call),
+                   alg, parts=int(meta.shape[0]))
+            del caches
+        except Exception as ex_:
+            out[name] = {"error": f"{type(ex_).__name__}: {ex_}"[:300]}
+        torch.cuda.empty_cache()
+    return out
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -448,6 +534,61 @@ def dense_roofline(dev, T=256):
     return res
 
 
+def fail_line(a, msg, rank=0):
+    """A failure of the launch itself is still ONE JSON line on stdout (rank 0) and a non-zero exit code — never a bare SystemExit."""
+    if rank == 0:
+        print(json.dumps({"metric": "decode tokens/s (MLA-attention-bound, 61 layers) + achieved HBM GB/s, DeepSeek-V3 MLA bs=128 seq=4k",
+                          "value": None, "unit": "tokens/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "error": msg}), flush=True)
+    sys.exit(2)
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(a):
+    """Re-run this script as `--gpus N` ranks of ONE node: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py <same arguments>.  The children inherit stdout: rank 0's JSON line is this process's line."""
+    import subprocess
+
+    if not a.dry_launch:
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n < a.gpus:
+            return fail_line(a, f"--gpus {a.gpus} but only {n} HIP device(s) are visible")
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL / peer mappings across processes need it on this driver
+    r = subprocess.run(cmd, env=env)
+    if r.returncode != 0:
+        fail_line(a, f"torch.distributed.run exited with code {r.returncode} (the ranks' own messages are on stderr)")
+    sys.exit(0)
+
+
+def dry_launch(a, world, rank):
+    """--dry-launch: the ranks meet over gloo (CPU), agree on their count with one all-reduce, rank 0 prints one line."""
+    import torch.distributed as dist
+
+    seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": a.gpus, "world_size": world, "ranks_seen": seen, "steps": a.steps, "warmup": a.warmup}),
+              flush=True)
+    sys.exit(0 if seen == world == a.gpus else 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -460,13 +601,23 @@ def main():
     ap.add_argument("--mode", choices=["mla", "cfg4"], default="mla",
                     help="mla (default): the headline DP-attention MLA decode bench; cfg4: BASELINE config 4, attention-TP + EP MoE "
                          "decoder layers with the path's collectives (all-gather, reduce-scatter, EP all-to-all) over RCCL")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch plumbing only: --gpus N ranks rendezvous over gloo on the CPU, rank 0 prints one line (no GPU needed)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` launches ITSELF: one rank per GPU under torch.distributed.run (what the driver's multi-GPU form does by
+        # hand); rank 0 of the children prints the one JSON line on this process's stdout.
+        return self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with WORLD_SIZE={a.gpus} (got {world})")
+        return fail_line(a, f"--gpus {a.gpus} but the launcher set WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}", rank)
+    if a.dry_launch:
+        return dry_launch(a, world, rank)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        return fail_line(a, f"rank {rank} needs device cuda:{local_rank}; {torch.cuda.device_count() if torch.cuda.is_available() else 0} visible", rank)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
@@ -640,6 +791,11 @@ def main():
         wl = None
         torch.cuda.empty_cache()
         variants = {"cfg2_ragged": k1_ragged_variant(dev)}
+        torch.cuda.empty_cache()
+        try:
+            variants.update(kernel_variants(dev))
+        except Exception as ex_:   # an add-on: never at the expense of the headline record
+            variants["kernel_variants_error"] = f"{type(ex_).__name__}: {ex_}"[:300]
         if step_variants is not None:
             variants["step"] = step_variants
         if os.environ.get("FLUENT_BENCH_CFG4_WORLD1", "1") != "0":
@@ -681,6 +837,11 @@ def main():
 
         budget = float(os.environ.get("FLUENT_BENCH_CFG4_TIMEOUT_S", "240"))
         line.update(_headline(tokens_per_s, world, a, ms_per_step, layers, graph_ok, roof, gemm, variants, cpu))
+        # the children build their own workload on the SAME GPU: the DP phase's 61 layer caches (20.6 GB), its graph and the graph pool go first
+        wl = graph = run = step = None   # noqa: F841
+        import gc
+
+        gc.collect()
         torch.cuda.empty_cache()
         cmd = [sys.executable, os.path.abspath(__file__), "--mode", "cfg4", "--gpus", str(world), "--steps", str(max(3, min(a.steps, 10))),
                "--warmup", "2"]

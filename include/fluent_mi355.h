@@ -35,6 +35,11 @@ typedef void* fl_stream_t;
 #define FL_KV_FP8_576 1       /* one fp8 [.,576] tensor, descale scalars */
 #define FL_KV_BF16_576 2      /* one bf16 [.,576] tensor */
 
+/* ABI version of THIS header.  A binding checks fl_version() == FL_ABI_VERSION once after loading the library, and every argument
+ * struct carries its own size (`struct_bytes`, first field) so that a caller compiled against another layout is refused with
+ * FL_ERR_INVALID instead of being read past its end.  101: FlMlaDecodeArgs gained struct_bytes (first) and block_table_cols (last);
+ * fl_topk_gate added. */
+#define FL_ABI_VERSION 101
 const char* fl_last_error(void);
 int fl_version(void);
 /* number of compute units of HIP device `device` (host query, cached) */
@@ -107,6 +112,7 @@ int fl_mla_dequant_gather(const void* k_lora_cache, const void* k_rope_cache, co
 /* ---- K1/K2: flash_mla_ckv_fp8_per_token / flash_mla_with_kvcache
  * (flashmla_backend.py:208-222,127-142 / :227-254,145-175) ---- */
 typedef struct FlMlaDecodeArgs {
+  int32_t struct_bytes;     /* = sizeof(FlMlaDecodeArgs) as the CALLER compiled it; anything else is refused */
   int32_t kv_format;        /* FL_KV_* */
   int32_t bs, s_q, h_q;     /* q rows per request = s_q*h_q (one latent KV head) */
   int32_t d_nope, d_rope;   /* 512, 64 */
@@ -313,6 +319,15 @@ int fl_moe_fused_gate(const float* logits, const float* bias, int64_t num_tokens
                       int topk_group, int topk, float routed_scaling_factor, int apply_routed_scaling_factor_on_output,
                       const int32_t* num_token_non_padded, float* topk_weights /*[T, topk]*/,
                       int32_t* topk_ids /*[T, topk]*/, fl_stream_t stream);
+
+/* ---- R1b: the plain (ungrouped) top-k routers imported beside it — flashinfer.topk_softmax (srt/layers/moe/topk.py:33, called by
+ * fused_topk :505-520; torch statement fused_topk_torch_native :463-495), flashinfer.routing_flash (LongCat-Flash router, :836-845;
+ * torch statement fused_topk_bias :51-70) and eps.utils.ops._ops.topk_sigmoid (:44-47).  logits f32 [T, E] (1 <= E <= 1024),
+ * bias f32 [E] or NULL; score_fn 0 = softmax over the row, 1 = sigmoid; choice = score + bias; top-k by choice (descending, ties ->
+ * lower expert id); weight = UNBIASED score, divided by the sum of the chosen scores if `renormalize`, times `scale`. ---- */
+int fl_topk_gate(const float* logits, const float* bias, int64_t num_tokens, int num_experts, int topk, int score_fn,
+                 int renormalize, float scale, float* topk_weights /*[T, topk]*/, int32_t* topk_ids /*[T, topk]*/,
+                 fl_stream_t stream);
 
 /* ---- R2: flashinfer.apply_rope_with_cos_sin_cache_inplace as RotaryEmbedding.forward_cuda calls it
  * (srt/layers/rotary_embedding.py:203-218) on q_pe / k_pe of the MLA path (models/deepseek_v2.py:646-647,695-696).

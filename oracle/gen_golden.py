@@ -250,6 +250,41 @@ def gen_router():
     print("router", sorted(k for k in out if k.endswith("_ids")))
 
 
+def gen_router_topk():
+    """The plain top-k routers' torch statements run from the reference's own source: fused_topk_native (moe/topk.py:73-91; the
+    statement behind flashinfer.topk_softmax, called by fused_topk :505-520) and fused_topk_bias (:51-70; the statement behind
+    flashinfer.routing_flash, LongCat-Flash :836-845).  Both carry @torch.compile in the source: the decorator is a no-op here."""
+    import typing
+    import torch.nn.functional as F
+
+    ns = {"torch": torch, "F": F, "Optional": typing.Optional, "ExpertLocationDispatchInfo": object,
+          "topk_ids_logical_to_physical": lambda ids, info: ids, "get_compiler_backend": lambda: "eager"}
+    path = "/root/reference/python/sglang/srt/layers/moe/topk.py"
+    real_compile = torch.compile
+    torch.compile = lambda *a, **k: (lambda f: f)
+    try:
+        native = _ref_import.load_function_from_source(path, "fused_topk_native", ns)
+        biased = _ref_import.load_function_from_source(path, "fused_topk_bias", ns)
+    finally:
+        torch.compile = real_compile
+    g = torch.Generator().manual_seed(43)
+    out = {}
+    for name, T, E, K, renorm in (("softmax_e128", 23, 128, 8, True), ("softmax_e8", 7, 8, 2, False), ("softmax_e256", 5, 256, 6, True),
+                                  ("softmax_e96", 11, 96, 4, True)):
+        logits = torch.randn(T, E, generator=g) * 2
+        w, ids = native(torch.empty(T, 1), logits, K, renorm)
+        out.update({f"{name}_logits": logits.numpy(), f"{name}_w": w.numpy(), f"{name}_ids": ids.numpy().astype(np.int32),
+                    f"{name}_cfg": np.array([K, int(renorm)], np.int32)})
+    for name, T, E, K, renorm in (("bias_longcat", 19, 768, 12, False), ("bias_e64", 9, 64, 6, True)):
+        logits = torch.randn(T, E, generator=g) * 2
+        bias = torch.randn(E, generator=g) * 0.01
+        w, ids = biased(torch.empty(T, 1), logits, bias, K, renorm)
+        out.update({f"{name}_logits": logits.numpy(), f"{name}_bias": bias.numpy(), f"{name}_w": w.numpy(),
+                    f"{name}_ids": ids.numpy().astype(np.int32), f"{name}_cfg": np.array([K, int(renorm)], np.int32)})
+    np.savez_compressed(os.path.join(OUT, "router_topk_plain.npz"), **out)
+    print("router_topk", sorted(k for k in out if k.endswith("_ids")))
+
+
 def gen_rope():
     """DeepseekScalingRotaryEmbedding (layers/rotary_embedding.py:719-846) run from the reference's own source: the YaRN
     cos/sin cache (fp32, as the CUDA path keeps it, :113-115) of a reduced config and forward_native on bf16 q_pe / k_pe —
@@ -462,6 +497,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-router" in sys.argv:
         gen_router()
+        gen_router_topk()
         sys.exit(0)
     if "--only-rmsnorm" in sys.argv:
         gen_rmsnorm()
@@ -472,6 +508,7 @@ if __name__ == "__main__":
     gen_gemm()
     gen_rmsnorm()
     gen_router()
+    gen_router_topk()
     gen_rope()
     gen_kv_move()
     if os.environ.get("TRITON_INTERPRET") == "1":

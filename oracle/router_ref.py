@@ -31,3 +31,22 @@ def biased_grouped_topk(logits, bias, num_expert_group, topk_group, topk, routed
     if num_token_non_padded is not None:
         ids[np.arange(T) >= int(num_token_non_padded), :] = -1                           # :673-680
     return w.astype(np.float32), ids
+
+
+def topk_plain(logits, topk, renormalize, bias=None, sigmoid=False, scale=1.0):
+    """The plain (ungrouped) routers of the same file: fused_topk_native (topk.py:73-91: softmax over the experts, torch.topk, optional
+    renormalisation — the statement behind flashinfer.topk_softmax) and fused_topk_bias (:51-70: selection by softmax + correction_bias,
+    weights = the unbiased scores — the statement behind flashinfer.routing_flash).  -> (weights f32 [T, topk], ids i32 [T, topk]), rows by
+    descending choice score (ties -> lower id).  sigmoid=True: eps' topk_sigmoid (unpinned, see fluent_mi355/router.py)."""
+    x = np.asarray(logits, np.float32).astype(np.float64)
+    if sigmoid:
+        scores = (1.0 / (1.0 + np.exp(-x))).astype(np.float32)
+    else:
+        e = np.exp(x - x.max(-1, keepdims=True))
+        scores = (e / e.sum(-1, keepdims=True)).astype(np.float32)                        # gating_output.softmax(dim=-1)
+    choice = scores if bias is None else scores + np.asarray(bias, np.float32)[None, :]   # :61
+    ids = np.argsort(-choice, axis=-1, kind="stable")[:, :topk]                           # :62 / :88
+    w = np.take_along_axis(scores, ids, axis=1)                                           # :63 (UNBIASED scores)
+    if renormalize:
+        w = w / w.sum(-1, keepdims=True, dtype=np.float32)                                # :65-66 / :89-90
+    return (w * np.float32(scale)).astype(np.float32), ids.astype(np.int32)

@@ -15,7 +15,7 @@ void fl_set_error(const char* fmt, ...) {
 
 extern "C" const char* fl_last_error(void) { return g_err; }
 
-extern "C" int fl_version(void) { return 100; }
+extern "C" int fl_version(void) { return FL_ABI_VERSION; }
 
 extern "C" int fl_device_cu_count(int device, int* cu_count) {
   static int cached[64];

@@ -959,6 +959,9 @@ int fl_mla_decode_bf16_impl(const FlMlaDecodeArgs* a, hipStream_t stream);   // 
 
 extern "C" int fl_mla_decode(const FlMlaDecodeArgs* args, fl_stream_t stream) {
   FL_CHECK_ARG(args != nullptr, "fl_mla_decode: null args");
+  FL_CHECK_ARG(args->struct_bytes == (int32_t)sizeof(FlMlaDecodeArgs),
+               "fl_mla_decode: FlMlaDecodeArgs.struct_bytes = %d, this library (ABI %d) expects %d — caller and library were built against "
+               "different include/fluent_mi355.h", args->struct_bytes, FL_ABI_VERSION, (int)sizeof(FlMlaDecodeArgs));
   switch (args->kv_format) {
     case FL_KV_FP8_PER_TOKEN:
     case FL_KV_FP8_576:

@@ -45,14 +45,11 @@ constexpr int kStgBytes = 512 + 16;                                // epilogue s
 static_assert(4 * 32 * kStgBytes <= kRingSlots * kSlotBytes, "epilogue staging fits the ring");
 
 constexpr int kPiecesPerWave = kDmaNopePerTile / 4;                // 8 LDS-DMA pieces of 1 KiB per PV wave and page
+constexpr unsigned long long kMergeTimeoutTicks = 200000000ull;    // 2 s of the 100 MHz wall clock: budget of the in-kernel split merge's poll
 
-#ifndef FL_Y_NOWAIT
-#define FL_Y_NOWAIT 0
-#endif
-#ifndef FL_Y_MID_BARRIER
-#define FL_Y_MID_BARRIER 0   // experiment (measured slower: 134.7 vs 127-133 us): second barrier per step between the QK
-                             // waves' MFMA chain and the PV waves' MFMAs
-#endif
+// (The experiment switches of rounds 2-4 — mid-step barrier, dual accumulate chain, lagged reference, tail loads inside the chain,
+//  L2 prefetch touches, DMA placement, the garbage-result bounding builds — live in probes/r05_k1_lab_switches.patch.txt with
+//  their measured results; the shipped file keeps the phase timer only.)
 #ifdef FL_MLA_TIMING
 __device__ int* g_dbg_y = nullptr;   // debug builds only: set by fl_mla_debug_set_buffer_y
 #define FL_T(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); tacc[i] += t__ - tlast; tlast = t__; } while (0)
@@ -65,15 +62,9 @@ __device__ int* g_dbg_y = nullptr;   // debug builds only: set by fl_mla_debug_s
 #endif
 
 // Rope A operand (4 bf16 k-steps) and raw k_scale of one page for one QK wave, held in registers two pages ahead.
-#ifndef FL_Y_PF
-#define FL_Y_PF 0   // > 0: every QK wave touches one dword per 128-B line of its quarter of the latent page FL_Y_PF pages
-                    // beyond the rope prefetch (page i + 2 + FL_Y_PF) — an L2 prefetch: the LDS ring cannot hold more
-                    // than ~1.5 pages in flight per CU, the L2 can
-#endif
 struct RopeRegs {
   uint4 ra[4];
   float ks;
-  unsigned pf;   // L2-prefetch touch (value unused)
 };
 
 struct QkLane {
@@ -93,9 +84,25 @@ __device__ __forceinline__ unsigned dn_off(const PvLane& lc, const int k) {
   return lc.dn_row + (unsigned)k * (FMT == 1 ? 1152u : 1024u) + (lc.dn_x ^ ((unsigned)k << 5));
 }
 
+__device__ __forceinline__ float fl_max3(const float a, const float b, const float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// the eight K operand chunk addresses of a lane (ring slot base included): chunk pair of k-step s (and s + 4 at + 256) at
+// kaddr[2 (s&3)], kaddr[2 (s&3) + 1].  base is a multiple of 16 KiB and kb0 < 16 KiB: (base + kb0) ^ c == base + (kb0 ^ c).
+__device__ __forceinline__ void qk_addr(int (&kaddr)[8], const int kb0_in, const int base) {
+  int b = kb0_in;
+  asm volatile("" : "+v"(b));   // opaque per pair: nothing derived from it is hoisted out of the page loop (and spilled)
+  b += base;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) kaddr[j] = b ^ (((j >> 1) << 6) | ((j & 1) << 4));
+}
+
 // scale triples {ks, log2 ks, 1/ks} of a QK wave's 32 tokens (lane li = token 32W + li) -> wave-private scratch
 __device__ __forceinline__ void scale_prep(float* __restrict__ scratch, float ks, const int tok0w, const int li, const int L) {
-  if (tok0w + li >= L || !(ks > 0.f) || !(ks < 3.0e38f)) ks = 1.f;
+  // (a usable scale is a positive normal / subnormal float: one v_cmp_class_f32)
+  ks = ((tok0w + li >= L) | !__builtin_amdgcn_classf(ks, 0x180)) ? 1.f : ks;
   // (both lane halves store the same values to the same addresses: no exec-mask branch)
   scratch[li] = ks;
   scratch[32 + li] = __builtin_amdgcn_logf(ks);
@@ -108,20 +115,16 @@ __device__ __forceinline__ void scale_prep(float* __restrict__ scratch, float ks
 //      go out behind the MFMA issue (into the registers the rope MFMAs just read), the normaliser sums and the next
 //      page's triples follow the P' store.  s_setprio 1 around the MFMA chain: the PV wave of this SIMD has its 8
 //      MFMAs ready at the same time, and they belong beside this wave's softmax, not inside its chain. ----
-__device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w, const QkLane& lc, const int lane,
+__device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w, const int (&kaddr)[8], const int koff, const int lane,
                                         const v8i (&qn)[8], const uint8_t* __restrict__ qr_lds, const float qs, RopeRegs& rr,
                                         const float ks_next, const uint8_t* __restrict__ rope_next,
-                                        const float* __restrict__ scale_next, const uint8_t* __restrict__ pf_next,
-                                        unsigned& pf_acc, const uint8_t* __restrict__ kp,
+                                        const float* __restrict__ scale_next, const uint8_t* __restrict__ kp,
                                         float* __restrict__ scratch, float* __restrict__ scratch_next,
                                         uint8_t* __restrict__ pbuf_w,
                                         float* __restrict__ ref_w, const int tok0w, const int L, const int L_row,
                                         const bool need_mask FL_T_PARAMS) {
   const int li = lane & 31, lh = lane >> 5;
-#ifndef FL_Y_QK_PRIO
-#define FL_Y_QK_PRIO 1   // 0: no priority; 1: QK waves at priority 1 during their MFMA chain; 2: always
-#endif
-  if (FL_Y_QK_PRIO == 1) __builtin_amdgcn_s_setprio(1);   // (a scheduling barrier for hipcc: it stays OUTSIDE the read / MFMA interleave below)
+  __builtin_amdgcn_s_setprio(1);   // (a scheduling barrier for hipcc: it stays OUTSIDE the read / MFMA interleave below)
   // ---- S^T[32 tok x 32 rows] = K . Q^T ----
   v16f acc;
 #pragma unroll
@@ -131,49 +134,21 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
   v8bf qr[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qr[s] = as_bf8(*reinterpret_cast<const uint4*>(qr_lds + s * 1024 + lane * 16));
-  if (FL_Y_PF > 0) pf_acc ^= rr.pf;   // (same age as the rope registers: no extra wait)
   uint4 ka[8][2];
-  int kb0 = lc.kb0;   // opaque per step: the derived k-step offsets are not kept live across steps
-  asm volatile("" : "+v"(kb0));
+  // K operand addresses: the eight swizzled 16-B chunk addresses of this lane's token row are formed ONCE PER PAIR of steps
+  // (qk_addr: 1 add + 7 xor) — the second step of a pair reads the next ring slot through the instruction's offset field
+  // (koff = 32 KiB), k-steps 4..7 through + 256.  Round 4 formed them per step (16 VALU of the QK wave's 133 per page).
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
-#ifdef FL_Y_HALFK   // experiment: half of the K operand reads (results are garbage)
-    if (s >= 4) { ka[s][0] = ka[s - 4][0]; ka[s][1] = ka[s - 4][1]; continue; }
-#endif
-    ka[s][0] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6)) + (s >> 2) * 256);
-    ka[s][1] = *reinterpret_cast<const uint4*>(kp + (kb0 ^ ((s & 3) << 6) ^ 16) + (s >> 2) * 256);
+    ka[s][0] = *reinterpret_cast<const uint4*>(kp + kaddr[(s & 3) * 2 + 0] + koff + (s >> 2) * 256);
+    ka[s][1] = *reinterpret_cast<const uint4*>(kp + kaddr[(s & 3) * 2 + 1] + koff + (s >> 2) * 256);
   }
-#ifndef FL_Y_DUAL_CHAIN
-#define FL_Y_DUAL_CHAIN 0
-#endif
-#if FL_Y_DUAL_CHAIN
-  // experiment (measured SLOWER: 136 vs 130 us; "operand reads + MFMA issue" 971 vs 771 cycles per step, drain 742 vs 625):
-  // two accumulate chains issued alternately, so that this wave always has a READY MFMA and its priority could keep the
-  // PV wave's MFMAs out of the chain.  The hypothesis behind it (a dependent MFMA loses the slot to the other wave's
-  // independent one every time) is therefore not what stretches the chain.
-  v16f acc2;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    if (s & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(rr.ra[s]), qr[s], acc2, 0, 0, 0);
-    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(rr.ra[s]), qr[s], acc, 0, 0, 0);
-  }
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    if (s & 1)
-      acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc2, 0, 0, 0, kUnitScale, 0, kUnitScale);
-    else
-      acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc, 0, 0, 0, kUnitScale, 0, kUnitScale);
-  }
-#else
 #pragma unroll
   for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(rr.ra[s]), qr[s], acc, 0, 0, 0);
 #pragma unroll
   for (int s = 0; s < 8; ++s)
     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(make_v8i(ka[s][0], ka[s][1]), qn[s], acc, 0, 0, 0, kUnitScale,
                                                           0, kUnitScale);
-#endif
   // operand reads: k-steps 0..3 before the rope MFMAs, k-step 4 + s behind the MFMA of k-step s (four k-steps = 32
   // registers in flight: with all eight hipcc runs out of registers beside Q and the two rope buffers)
   __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // DS reads: Q rope fragments, k-steps 0..3
@@ -188,71 +163,24 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
     ks4[g] = *reinterpret_cast<const float4*>(scratch + tb);
     lk4[g] = *reinterpret_cast<const float4*>(scratch + 32 + tb);
   }
-#ifndef FL_Y_TRIPLES_IN_CHAIN
-#define FL_Y_TRIPLES_IN_CHAIN 1
-#endif
-#ifndef FL_Y_TAIL_IN_CHAIN
-#define FL_Y_TAIL_IN_CHAIN 0   // experiment (measured: no gain, 133-135 vs 130-135 us): the rope / scale loads of page i+2 and
-                               // the scale triples of page i+1 issued INSIDE this step's MFMA chain instead of behind it.  The
-                               // phase timer shows why: the chain phase grows by exactly what the tail shrinks (771 -> 1083
-                               // cycles; tail 217 -> 81, rope loads 119 -> 4) — the chain's issue slots are not free
-#endif
-#ifndef FL_Y_TAIL_GROUPS
-#define FL_Y_TAIL_GROUPS 0
-#endif
-#if FL_Y_TAIL_IN_CHAIN
-  // rope A operand / raw scale of page i+2 into the registers the rope MFMAs have read (UNCONDITIONAL, see below)
 #pragma unroll
-  for (int s = 0; s < 4; ++s) rr.ra[s] = *reinterpret_cast<const uint4*>(rope_next + s * 32);
-  rr.ks = *scale_next;
-  if (FL_Y_PF > 0) rr.pf = *reinterpret_cast<const unsigned*>(pf_next);
-  scale_prep(scratch_next, ks_next, tok0w + kPage, li, L);
-#endif
-#pragma unroll
-  for (int s = 0; s < (FL_Y_TRIPLES_IN_CHAIN ? 8 : 4); ++s) {
+  for (int s = 0; s < 8; ++s) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#if FL_Y_TAIL_IN_CHAIN
-#if FL_Y_TAIL_GROUPS == 1
-    if (s == 1) __builtin_amdgcn_sched_group_barrier(0x020, 5, 0);   // VMEM reads: rope + scale of page i+2
-#elif FL_Y_TAIL_GROUPS == 2
-    if (s == 7) __builtin_amdgcn_sched_group_barrier(0x020, 5, 0);
-#endif
-#endif
   }
-  if (!FL_Y_TRIPLES_IN_CHAIN) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
   __builtin_amdgcn_sched_barrier(0);
-  if (FL_Y_QK_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(0);
   FL_T(6);   // operand reads + MFMA issue
-#if FL_Y_MID_BARRIER
-  // M_i: this wave's chain is in the matrix pipe; only now do the PV waves issue their MFMAs.  A dependent MFMA becomes
-  // ready just as its predecessor leaves the pipe, so an independent MFMA of the SIMD's other wave wins the slot every
-  // time (priority does not help: nothing of this wave is ready at that moment) and the 12-deep chain took the time of
-  // all 20 MFMAs (measured) while its softmax then found the pipe idle.
-  __builtin_amdgcn_s_barrier();
-  FL_T(11);  // mid-step barrier
-#endif
   // rope A operand / raw scale of page i+2 into the registers the rope MFMAs have read: token 32W + li, 16-B chunks
   // 2s + lh of its 128-B row.  UNCONDITIONAL (the caller clamps the page into the part): behind a conditional load hipcc
   // can only wait with vmcnt(0), which would expose the whole latency of the loads issued one step earlier, every step
-#if !FL_Y_TAIL_IN_CHAIN
 #pragma unroll
   for (int s = 0; s < 4; ++s) rr.ra[s] = *reinterpret_cast<const uint4*>(rope_next + s * 32);
   rr.ks = *scale_next;
-  if (FL_Y_PF > 0) rr.pf = *reinterpret_cast<const unsigned*>(pf_next);
   __builtin_amdgcn_sched_barrier(0);
-#endif
   FL_T(8);   // rope / scale load issue
 
   // ---- online softmax of the block; tokens of lane: 32W + 8g + 4lh + e ----
-#if FL_Y_DUAL_CHAIN
-#pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    const float2v t = float2v{acc[r], acc[r + 1]} + float2v{acc2[r], acc2[r + 1]};
-    acc[r] = t[0];
-    acc[r + 1] = t[1];
-  }
-#endif
   float tmax = -INFINITY;
   if (!need_mask) {
     // PACKED f32 math (v_pk_mul_f32 / v_pk_fma_f32: two elements per instruction).  Beside a running MFMA a VALU
@@ -269,7 +197,7 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
       acc[g * 4 + 1] = y01[1];
       acc[g * 4 + 2] = y23[0];
       acc[g * 4 + 3] = y23[1];
-      tmax = fmaxf(fmaxf(tmax, fmaxf(y01[0], y01[1])), fmaxf(y23[0], y23[1]));
+      tmax = fl_max3(fl_max3(tmax, y01[0], y01[1]), y23[0], y23[1]);   // (two v_max3_f32 per four scores)
     }
   } else {
 #pragma unroll
@@ -297,15 +225,6 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
     tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
   }
   FL_T(7);   // MFMA drain + scaling + max
-#ifndef FL_Y_LAG_REF
-#define FL_Y_LAG_REF 0   // experiment (round 3, measured SLOWER at cfg2: 131.6-134.8 vs 127.7-129.0 us per launch on one box; H = 16
-                         // and bs = 16 unchanged — profiles/r03_k1_lag_ref_ab.txt): the exponentials taken against the reference
-                         // CARRIED IN (m_w), which does not depend on this block's maximum, so that the 16 exp2 / 8 e4m3
-                         // conversions are independent of the max chain and the lane-half exchange; when a block's maximum
-                         // moves the reference (tmax > m_w: rare after the first page) the wave repeats them.  Same P' bytes,
-                         // references and sums as the in-order form.  The extra issue slots (the fast-path exponentials of the
-                         // first pages are thrown away, the vote + branch) cost more than the dependency stalls they fill.
-#endif
   float m_new = tmax > m_w ? ceilf(tmax) + kRefHeadroom : m_w;
   float ev[16];
   int pk[4];
@@ -318,16 +237,13 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
       ev[g * 4 + 1] = __builtin_amdgcn_exp2f(a01[1]);
       ev[g * 4 + 2] = __builtin_amdgcn_exp2f(a23[0]);
       ev[g * 4 + 3] = __builtin_amdgcn_exp2f(a23[1]);
-      const int v = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 0], ev[g * 4 + 1], 0, false);
+      // (low half written first, high half second: the "old" operand is a score that dies here — its register becomes the
+      //  destination, no v_mov 0 for the half the first conversion leaves untouched)
+      const int v = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 0], ev[g * 4 + 1], __float_as_int(acc[g * 4 + 0]), false);
       pk[g] = __builtin_amdgcn_cvt_pk_fp8_f32(ev[g * 4 + 2], ev[g * 4 + 3], v, true);
     }
   };
-  if (FL_Y_LAG_REF) {
-    expo(kPShift - m_w);                 // (first block of a row: m_w = kNegRef, garbage — always repeated below)
-    if (__any(m_new != m_w)) expo(kPShift - m_new);
-  } else {
-    expo(kPShift - m_new);
-  }
+  expo(kPShift - m_new);
   // publish P' (16 B per lane) and the block reference for the PV waves of this row tile
   *reinterpret_cast<uint4*>(pbuf_w + lane * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
   ref_w[li] = m_new;   // (identical in both lane halves)
@@ -352,9 +268,7 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
     l_run = l2[0] + l2[1];
     lq_run = q2[0] + q2[1];
   }
-#if !FL_Y_TAIL_IN_CHAIN
   scale_prep(scratch_next, ks_next, tok0w + kPage, li, L);
-#endif
 }
 
 // ---- PV wave: O^T[256 dims x 32 rows] += V^T(page) . P^T, with the LDS-DMA refill of a later page in the MFMA shadow ----
@@ -363,7 +277,13 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
 // touches O in the page loop (a conditional rescale makes hipcc copy all 128 O registers at the join, every page).  Only
 // a reference more than kMaxUp above m_o cannot be represented: it raises `redo` and the workgroup repeats the request
 // with m_o preset to the final reference.
-constexpr float kMaxUp = 64.f;
+// The reference is set kRefLift ABOVE the first block's (a power-of-two rescale of O: exact, fp32 has the range both ways), so that
+// a later block may exceed the first by kRefLift + kMaxUp = 128 log2 units (89 nats) before the pass is repeated: with the
+// first block's own reference (round 2-4) any logit spread beyond 2^64 between a row's first block and its maximum doubled the
+// request's time (seen at BASELINE config 4 with random projection weights: 0.87 instead of 0.47 ms per launch).
+// Overflow bound: |O| <= 2^6 (P') x 2^9 (fp8 V) x 2^17 tokens x 2^kMaxUp = 2^120.
+constexpr float kMaxUp = 88.f;
+constexpr float kRefLift = 40.f;
 template <bool DMA, int FMT>
 __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, const PvLane& lc_in, const int lane,
                                         const uint8_t* __restrict__ vp, const uint8_t* __restrict__ pbuf_rt,
@@ -377,24 +297,9 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, con
   const uint4 p1 = *reinterpret_cast<const uint4*>(pbuf_rt + 64 * 16 + lane * 16);
   const float m0 = ref_rt[li];
   const float m1 = ref_rt[32 + li];
-  // the refill goes out FIRST: its lead over the page's first reader is what hides the memory latency, and it keeps this
-  // wave's MFMAs out of the QK chain of the SIMD's other wave
-#ifndef FL_Y_DMA_FIRST
-#define FL_Y_DMA_FIRST (FL_Y_MID_BARRIER ? 8 : 0)   // pieces issued before the P' / V^T reads (with the mid-step barrier
-                                                    // this wave has nothing else to do until the QK chains are issued);
-                                                    // the rest goes out one behind each PV MFMA
-#endif
-#if !defined(FL_Y_NODMA) && !defined(FL_Y_NOPV)
-  if (DMA) {
-#pragma unroll
-    for (int k = 0; k < FL_Y_DMA_FIRST; ++k) fl_dma16_s(src_nope, dn_off<FMT>(lc, k), dma_dst + k * 1024);
-  }
-#endif
+  // (the refill goes out one piece behind each PV MFMA)
   v8i va[8];
   auto load_vt = [&](int jb) {
-#ifdef FL_Y_HALFV   // experiment: half of the V^T operand reads (results are garbage)
-    if (jb & 1) { va[jb] = va[jb - 1]; return; }
-#endif
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint8_t* ap = vp + (lc.vb0 ^ (((jb & 3) << 4) | ((jb >> 2) << 7))) + (u & 1) * (16 * kDN) + (u >> 1) * (32 * kDN);
@@ -406,34 +311,20 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, con
   load_vt(0);
   load_vt(1);
   load_vt(2);
-#ifdef FL_Y_NOPV   // experiment: PV waves without V^T reads and MFMAs (results are garbage)
-  if (DMA) {
-#pragma unroll
-    for (int jb = 0; jb < 8; ++jb) fl_dma16_s(src_nope, dn_off<FMT>(lc, jb), dma_dst + jb * 1024);
-  }
-  m_o = fmaxf(m_o, m0 + m1 + __uint_as_float(p0.x ^ p1.x));
-  return;
-#endif
   const float mw_max = fmaxf(m0, m1);
-  m_o = m_o > kNegRef ? m_o : mw_max;
+  m_o = m_o > kNegRef ? m_o : (mw_max > kNegRef ? mw_max + kRefLift : kNegRef);
   redo |= (mw_max - m_o > kMaxUp) ? 1 : 0;
   int sb = 127 + (int)fminf((lh ? m1 : m0) - m_o, kMaxUp);
   sb = sb < 0 ? 0 : sb;
   const v8i pb = make_v8i(p0, p1);
-#if FL_Y_MID_BARRIER
-  __builtin_amdgcn_s_barrier();   // M_i: the QK chains are issued
-  FL_T(6);
-#endif
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
     if (jb + 3 < 8) load_vt(jb + 3);
     o[jb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[jb], pb, o[jb], 0, 0, 0, kUnitScale, 0, sb);
-#if !defined(FL_Y_NODMA)
-    if (DMA && jb >= FL_Y_DMA_FIRST) fl_dma16_s(src_nope, dn_off<FMT>(lc, jb), dma_dst + jb * 1024);
-#endif
+    if (DMA) fl_dma16_s(src_nope, dn_off<FMT>(lc, jb), dma_dst + jb * 1024);
   }
   // V^T operand reads three tiles ahead of their MFMA
-  if (!FL_Y_MID_BARRIER) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
   for (int jb = 0; jb < 5; ++jb) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -613,8 +504,6 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       lc.kb0 = li * kDN + (((((kx >> 2)) << 2) | ((2 * lh) ^ (kx & 3))) << 4);
     }
     float* scratch = reinterpret_cast<float*>(smem + kOffScratch + w4 * kScratchPerWave);
-    unsigned pf_acc = 0;
-    if (FL_Y_QK_PRIO == 2) __builtin_amdgcn_s_setprio(1);
     for (; req < p.bs; ++req, tile_b = 0) {
       FL_Y_REQUEST_HEAD();
       // Q fragments (B operands), once per request
@@ -713,9 +602,6 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       // rope A operand of this lane: token 32W + li, 16-B chunks 2s + lh of its 128-B row; raw scale of token 32W + li.
       // Every load is UNCONDITIONAL (page index clamped into the part; an empty part reads the padding page 0).
       auto rope_src = [&](const int t) {
-#ifdef FL_Y_ROPE1LINE   // experiment: every lane reads the same 32 B of the page (one 128-B line per instruction; results are garbage)
-        return reinterpret_cast<const uint8_t*>(g_k_rope) + (page_of(t) * kPage + 32 * W) * (kDR * 2) + lh * 16;
-#endif
         if constexpr (FMT == 1)   // bytes 512 + 32 lh .. of the token's 576-B row: the rope k-step's A operand
           return g_k_nope + (page_of(t) * kPage + 32 * W + li) * (long long)(kDN + kDR) + kDN + lh * 32;
         return reinterpret_cast<const uint8_t*>(g_k_rope) + (page_of(t) * kPage + 32 * W + li) * (kDR * 2) + lh * 16;
@@ -732,7 +618,6 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           for (int s = 0; s < 4; ++s) r.ra[s] = *reinterpret_cast<const uint4*>(rp + s * 32);
           r.ks = *scale_src(t);
         }
-        r.pf = 0;
       };
       for (int pass = 0; pass < 2; ++pass) {
         float l_run = 0.f, lq_run = 0.f, m_w = kNegRef;
@@ -748,14 +633,12 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
         FL_T(5);   // request prologue
 
         // step i uses `rr` (page i) and refills it with page i+2; `rn` holds page i+1
-        auto step = [&](const int i, RopeRegs& rr, const RopeRegs& rn) {
+        int kaddr[8];
+        auto step = [&](const int i, RopeRegs& rr, const RopeRegs& rn, const int koff) {
           if (i + 2 >= win_base + 64 && i + 2 < n) load_window(i + 2);   // pages i+2 .. i+65
           const int t2 = i + 2 < n ? i + 2 : n - 1;
           const uint8_t* rope_next = rope_src(t2);
           const float* scale_next = FMT == 0 ? scale_src(t2) : nullptr;
-          int t3 = i + 2 + FL_Y_PF < n ? i + 2 + FL_Y_PF : n - 1;   // L2-prefetch target (inside the page-id window)
-          t3 = t3 < win_base + 64 ? t3 : win_base + 63;
-          const uint8_t* pf_next = g_k_nope + page_of(t3) * (long long)(kPage * kDN) + w4 * 8192 + lane * 128;
           FL_T(2);   // (loop control)
           __builtin_amdgcn_s_barrier();   // B_i: page i landed, P buffers of parity i free
           FL_T(0);   // barrier
@@ -767,8 +650,8 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
                      smem + kOffPbuf + (i & 1) * kPbufPerParity + (rt * 2 + W) * (64 * 16),
                      reinterpret_cast<float*>(smem + kOffRef + (i & 1) * kRefPerParity) + (rt * 2 + W) * 32, tok0w, L_row, need_mask);
           else
-          qk_step(l_run, lq_run, m_w, lc, lane, qn, qr_lds, qs, rr, rn.ks, rope_next, scale_next, pf_next, pf_acc,
-                  smem + kOffRing + (i & 3) * kSlotBytes + W * (32 * kDN), scratch + (i & 1) * 96, scratch + ((i + 1) & 1) * 96,
+          qk_step(l_run, lq_run, m_w, kaddr, koff, lane, qn, qr_lds, qs, rr, rn.ks, rope_next, scale_next,
+                  smem, scratch + (i & 1) * 96, scratch + ((i + 1) & 1) * 96,
                   smem + kOffPbuf + (i & 1) * kPbufPerParity + (rt * 2 + W) * (64 * 16),
                   reinterpret_cast<float*>(smem + kOffRef + (i & 1) * kRefPerParity) + (rt * 2 + W) * 32, tok0w, L, L_row,
                   need_mask FL_T_ARGS);
@@ -780,16 +663,18 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           // pairs of steps without a condition in between (a skipped second step would leave a path with nothing issued
           // behind rA's loads: vmcnt(0) again), then the odd tail
           int i = 0;
+          // (i even: ring slot i & 3 is 0 or 2; the odd step of the pair reads slot + 1 through the offset field)
           for (; i + 1 < n; i += 2) {
-            step(i, rA, rB);
-            step(i + 1, rB, rA);
+            qk_addr(kaddr, lc.kb0, kOffRing + (i & 2) * kSlotBytes + W * (32 * kDN));
+            step(i, rA, rB, 0);
+            step(i + 1, rB, rA, kSlotBytes);
           }
-          if (i < n) step(i, rA, rB);
+          if (i < n) {
+            qk_addr(kaddr, lc.kb0, kOffRing + (i & 2) * kSlotBytes + W * (32 * kDN));
+            step(i, rA, rB, 0);
+          }
         }
         __builtin_amdgcn_s_barrier();   // B_n: the PV waves run PV(n-1)
-#if FL_Y_MID_BARRIER
-        __builtin_amdgcn_s_barrier();   // M_n
-#endif
         // normalisers of this wave's blocks -> LDS for the PV waves' epilogue
         {
           const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -808,7 +693,6 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
         if ((redo_flag[0] | redo_flag[1] | redo_flag[2] | redo_flag[3]) == 0) break;   // workgroup-uniform
       }
     }
-    asm volatile("" ::"v"(pf_acc));   // (keeps the prefetch touches alive)
 #ifdef FL_MLA_TIMING
     if (g_dbg_y != nullptr && lane == 0) {
       unsigned long long* d = reinterpret_cast<unsigned long long*>(g_dbg_y) + ((long long)blockIdx.x * 8 + wave_id) * 14;
@@ -892,8 +776,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       // joined inside a loop make hipcc copy the O registers at the join).
 #define FL_Y_PV_STEP(HAS_PREV, HAS_DMA)                                                                                \
   {                                                                                                                    \
-    if (FL_Y_NOWAIT) { /* experiment: timing without the page-landed wait (results are garbage) */                     \
-    } else if (i + 1 < n) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* page i landed, page i+1 may stay in flight */ \
+    if (i + 1 < n) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* page i landed, page i+1 may stay in flight */      \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
     FL_T(0); /* page-landed wait */                                                                                    \
@@ -911,7 +794,6 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       if (HAS_DMA) {                                                                                                   \
         _Pragma("unroll") for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s(sn, dn_off<FMT>(lc, k), dst + k * 1024);      \
       }                                                                                                                \
-      if (FL_Y_MID_BARRIER) __builtin_amdgcn_s_barrier(); /* M_i */                                                    \
     }                                                                                                                  \
     /* tail of the sequence: zero the rows of page i past the end (P' is exactly 0 there, but 0 * NaN from stale fp8   \
        NaN patterns would poison the PV MFMA of the next step); the QK waves mask those tokens by index */             \
@@ -1055,9 +937,18 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
         const int sh = 16 * (rgrp & 1);
         const int tgt = 4 * (nsplit - 1);
         FL_T(4);   // epilogue
-        while (((arrived >> sh) & 0xffff) != tgt) {
-          __builtin_amdgcn_s_sleep(2);
-          arrived = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // BOUNDED poll: the counter must be exactly 0 at entry (K3 zeroes it, the merging workgroup puts it back) and launches that
+        // share one metadata tensor must be ordered on one stream (include/fluent_mi355.h) — a stale or double count (an aborted launch, two
+        // concurrent launches on one tensor) would otherwise spin forever.  After kMergeTimeoutTicks of the 100 MHz wall clock the merge gives
+        // up and POISONS its rows and LSEs with NaN: a visible wrong answer, not a hung GPU.
+        bool merge_timed_out = false;
+        {
+          const unsigned long long t_poll = wall_clock64();
+          while (((arrived >> sh) & 0xffff) != tgt) {
+            __builtin_amdgcn_s_sleep(2);
+            arrived = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wall_clock64() - t_poll > kMergeTimeoutTicks) { merge_timed_out = true; break; }
+          }
         }
         FL_T(7);   // merging piece: wait for the other pieces
         if (lane == 0) {   // the last of the four PV waves past the poll puts the counter back (the same metadata serves every layer's launch)
@@ -1121,10 +1012,10 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           den += mx == -INFINITY ? 0.f : __expf(ld_agent_f32(la) - mx);
           denx += mxx == -INFINITY ? 0.f : __expf(ld_agent_f32(la + 1) - mxx);
         }
-        const float invd = den > 0.f ? 1.f / den : 0.f;
+        const float invd = merge_timed_out ? __builtin_nanf("") : (den > 0.f ? 1.f / den : 0.f);
         if (row_ok && lh == 0 && W == 0) {
           const unsigned j = (unsigned)row / (unsigned)p.h_q, h = (unsigned)row - j * (unsigned)p.h_q;
-          p.lse[((long long)req * p.h_q + h) * p.s_q + j] = denx > 0.f ? mxx + __logf(denx) : -INFINITY;
+          p.lse[((long long)req * p.h_q + h) * p.s_q + j] = merge_timed_out ? __builtin_nanf("") : (denx > 0.f ? mxx + __logf(denx) : -INFINITY);
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {

@@ -84,6 +84,79 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__
     id_out[t * topk + lane] = padded ? -1 : my_id;
   }
 }
+
+// R1b — plain (ungrouped) top-k routers of the same file: flashinfer.topk_softmax (fused_topk, topk.py:505-520; torch statement
+// fused_topk_torch_native :463-495), flashinfer.routing_flash (LongCat-Flash, topk.py:836-845; torch statement fused_topk_bias
+// :51-70) and eps' topk_sigmoid (resolved at topk.py:44-47).  score = softmax / sigmoid of the row (fp32), choice = score (+ bias),
+// top-k by choice (value descending, expert id ascending on ties), weight = the UNBIASED score, optionally divided by the sum of
+// the chosen scores, times `scale`.  Same one-wave-per-token shuffle structure as the grouped kernel; any E <= 1024.
+template <int V>
+__global__ __launch_bounds__(256) void topk_gate_kernel(const float* __restrict__ logits, const float* __restrict__ bias, long long T,
+                                                        int E, int topk, int sigmoid, int renorm, float scale,
+                                                        float* __restrict__ w_out, int* __restrict__ id_out) {
+  const int lane = threadIdx.x & 63;
+  const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  float s[V], c[V];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int e = lane * V + i;
+    s[i] = e < E ? logits[t * E + e] : -INFINITY;
+    mx = fmaxf(mx, s[i]);
+  }
+  if (sigmoid) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) s[i] = lane * V + i < E ? 1.f / (1.f + expf(-s[i])) : 0.f;
+  } else {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      s[i] = lane * V + i < E ? expf(s[i] - mx) : 0.f;
+      den += s[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o);
+#pragma unroll
+    for (int i = 0; i < V; ++i) s[i] = s[i] / den;
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int e = lane * V + i;
+    c[i] = e < E ? s[i] + (bias != nullptr ? bias[e] : 0.f) : -INFINITY;
+  }
+  float my_w = 0.f, sum = 0.f;
+  int my_id = -1;
+  for (int j = 0; j < topk; ++j) {
+    float bv = -INFINITY, bs = 0.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const bool better = c[i] > bv;
+      bv = better ? c[i] : bv;
+      bi = better ? lane * V + i : bi;
+      bs = better ? s[i] : bs;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o), os = __shfl_xor(bs, o);
+      const int oi = __shfl_xor(bi, o);
+      const bool take = ov > bv || (ov == bv && oi < bi);
+      bv = take ? ov : bv; bi = take ? oi : bi; bs = take ? os : bs;
+    }
+    if (bi == 0x7fffffff) bi = -1;
+#pragma unroll
+    for (int i = 0; i < V; ++i) c[i] = (lane * V + i == bi) ? -INFINITY : c[i];
+    if (lane == j) { my_w = bs; my_id = bi; }
+    sum += bi >= 0 ? bs : 0.f;
+  }
+  if (lane < topk) {
+    w_out[t * topk + lane] = (renorm ? my_w / sum : my_w) * scale;
+    id_out[t * topk + lane] = my_id;
+  }
+}
 }  // namespace
 
 extern "C" int fl_moe_fused_gate(const float* logits, const float* bias, int64_t num_tokens, int num_experts,
@@ -115,5 +188,28 @@ extern "C" int fl_moe_fused_gate(const float* logits, const float* bias, int64_t
   }
 #undef FL_GATE
   FL_CHECK_LAUNCH("fl_moe_fused_gate");
+  return FL_OK;
+}
+
+extern "C" int fl_topk_gate(const float* logits, const float* bias, int64_t num_tokens, int num_experts, int topk, int score_fn,
+                            int renormalize, float scale, float* topk_weights, int32_t* topk_ids, fl_stream_t stream) {
+  FL_CHECK_ARG(logits && topk_weights && topk_ids, "fl_topk_gate: null pointer");
+  FL_CHECK_ARG(num_tokens >= 0 && num_experts >= 1 && num_experts <= 64 * kMaxV, "fl_topk_gate: num_experts=%d must be in 1..%d",
+               num_experts, 64 * kMaxV);
+  FL_CHECK_ARG(topk >= 1 && topk <= 64 && topk <= num_experts, "fl_topk_gate: topk=%d out of range", topk);
+  FL_CHECK_ARG(score_fn == 0 || score_fn == 1, "fl_topk_gate: score_fn must be 0 (softmax) or 1 (sigmoid)");
+  if (num_tokens == 0) return FL_OK;
+  const dim3 grid((unsigned)((num_tokens + 3) / 4)), block(256);
+  const int v = (num_experts + 63) / 64;
+#define FL_TOPK(V_)                                                                                                       \
+  topk_gate_kernel<V_><<<grid, block, 0, (hipStream_t)stream>>>(logits, bias, num_tokens, num_experts, topk, score_fn,    \
+                                                                 renormalize ? 1 : 0, scale, topk_weights, topk_ids)
+  if (v <= 1) FL_TOPK(1);
+  else if (v <= 2) FL_TOPK(2);
+  else if (v <= 4) FL_TOPK(4);
+  else if (v <= 8) FL_TOPK(8);
+  else FL_TOPK(16);
+#undef FL_TOPK
+  FL_CHECK_LAUNCH("fl_topk_gate");
   return FL_OK;
 }

@@ -3,16 +3,18 @@ the FP8 MLA-decode / grouped-GEMM hot path: quantization.quant
 silu_and_mul, activation.silu_and_mul_fuse_block_quant, comm.trtllm_{allreduce,reducescatter,allgather}_fusion, and
 moe_fused_gate (the router selection feeding the EP dispatch, srt/layers/moe/topk.py:33,715) and
 apply_rope_with_cos_sin_cache_inplace (q_pe / k_pe rotation before K5/K4, srt/layers/rotary_embedding.py:31,203), plus the
+rmsnorm / fused_add_rmsnorm / norm._rmsnorm_fused_parallel (layernorm.py:26-31,293), topk_softmax / routing_flash (topk.py:33,845), the
 two attention-wrapper classes FlashMLABackend's base class constructs (flashinfer_mla_backend.py:124-142) as INERT objects
 (attention_wrappers.py) and `comm.vllm_ar` (C4).  Sampling / norm / prefill attention are out of scope (not named by the
 north star)."""
 from fluent_mi355.gemm import sgl_per_token_group_quant_fp8, silu_and_mul  # noqa: F401
-from fluent_mi355.router import moe_fused_gate  # noqa: F401
+from fluent_mi355.router import moe_fused_gate, routing_flash, topk_softmax  # noqa: F401
 from fluent_mi355.rope import FusedSetKVBufferArg, apply_rope_with_cos_sin_cache_inplace  # noqa: F401
 
 from .attention_wrappers import BatchMLAPagedAttentionWrapper, BatchPrefillWithRaggedKVCacheWrapper  # noqa: F401
 
-from . import activation, comm, quantization  # noqa: F401
+from . import activation, comm, norm, quantization  # noqa: F401
+from .norm import fused_add_rmsnorm, gemma_fused_add_rmsnorm, gemma_rmsnorm, rmsnorm  # noqa: F401
 
 import torch as _torch
 

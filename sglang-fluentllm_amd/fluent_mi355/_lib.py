@@ -6,6 +6,7 @@ import torch
 LIB_PATH = os.environ.get("FLUENT_MI355_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                                             "libfluent_mi355.so")
 
+ABI_VERSION = 101   # include/fluent_mi355.h: FL_ABI_VERSION
 _c_void_p = ctypes.c_void_p
 _i32p = ctypes.c_void_p
 _f32p = ctypes.c_void_p
@@ -15,7 +16,7 @@ class FlMlaDecodeArgs(ctypes.Structure):
     """Mirror of `struct FlMlaDecodeArgs` in include/fluent_mi355.h (field order is ABI)."""
 
     _fields_ = [
-        ("kv_format", ctypes.c_int32), ("bs", ctypes.c_int32), ("s_q", ctypes.c_int32), ("h_q", ctypes.c_int32),
+        ("struct_bytes", ctypes.c_int32), ("kv_format", ctypes.c_int32), ("bs", ctypes.c_int32), ("s_q", ctypes.c_int32), ("h_q", ctypes.c_int32),
         ("d_nope", ctypes.c_int32), ("d_rope", ctypes.c_int32), ("causal", ctypes.c_int32),
         ("num_parts", ctypes.c_int32),
         ("softmax_scale", ctypes.c_float), ("descale_q", _f32p), ("descale_k", _f32p),
@@ -37,6 +38,9 @@ def _load():
     lib_ = ctypes.CDLL(LIB_PATH)
     lib_.fl_last_error.restype = ctypes.c_char_p
     lib_.fl_version.restype = ctypes.c_int
+    if lib_.fl_version() != ABI_VERSION:
+        raise RuntimeError(f"fluent_mi355: {LIB_PATH} reports ABI {lib_.fl_version()}, this binding was written for {ABI_VERSION} "
+                           "(include/fluent_mi355.h: FL_ABI_VERSION) — rebuild the library")
     lib_.fl_device_cu_count.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     lib_.fl_mla_num_parts.argtypes = [ctypes.c_int, ctypes.c_int]
     lib_.fl_mla_get_metadata.argtypes = [_i32p, ctypes.c_int, ctypes.c_int, _i32p, _i32p, _c_void_p]

@@ -49,11 +49,13 @@ _splitk_ws = {}
 
 
 def _router_workspace(device, nbytes):
-    """f32 partials of the split-K router GEMM: one buffer per (device, stream), grown on demand"""
-    capturing = torch.cuda.is_current_stream_capturing()
-    # (a buffer allocated during hipGraph capture lives in the graph's private pool: it must not be handed to eager calls, and an
-    #  eager buffer must not be replaced from inside a capture — the two kinds are kept apart; ADVICE r3)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr(device), capturing)
+    """f32 partials of the split-K router GEMM.  Eager calls share one buffer per (device, stream), grown on demand.  A call made while
+    the stream is CAPTURING gets a fresh buffer every time: it comes out of the graph's private pool and the graph owns it — nothing
+    allocated under one capture is handed to another capture (another pool; the first graph may be gone) or replaced while earlier
+    captured kernels still point at it."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr(device))
     ws = _splitk_ws.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = _splitk_ws[key] = torch.empty(max(nbytes, 8 << 20), dtype=torch.uint8, device=device)

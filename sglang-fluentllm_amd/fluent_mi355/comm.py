@@ -519,3 +519,72 @@ class TPDPConvertor:
             ctx.output().copy_(ctx.input())
             return
         _gather_rows_uneven(ctx.input(), ctx.counts, self.rank, sum(ctx.counts), self.group, out=ctx.output())
+
+
+# ---- eps.communication.MscclppCommunicator / MscclppCommunicatorParams (srt/distributed/parallel_state.py:52,963-977) ----
+# The reference builds ONE communicator per process at start-up — rank 0 draws `createUniqueId()`, broadcasts it over the CPU group, every
+# rank constructs `MscclppCommunicator(unique_id, MscclppCommunicatorParams(rank, world_size, num_ranks_per_node))` — and hands it on as
+# `comm.data_ptr()` to eps.fast_ep.AllToAll (moe/dispatcher/fast_ep.py:15-22) and as the object itself to TPDPConvertor.Params
+# (dp_attention.py:64-72).  MI355X: the transport is torch.distributed over RCCL / xGMI (+ the peer-mapped one-shot kernels), so the
+# communicator is a HOST object that names the process group the exchanges run on; `data_ptr()` is a key into a process-local registry
+# from which AllToAll recovers the object.
+_communicators = {}
+
+
+class MscclppCommunicatorParams:
+    def __init__(self, rank, world_size, num_ranks_per_node):
+        self.rank, self.world_size, self.num_ranks_per_node = int(rank), int(world_size), int(num_ranks_per_node)
+        if not (0 <= self.rank < self.world_size) or self.num_ranks_per_node < 1:
+            raise ValueError(f"MscclppCommunicatorParams: rank {rank} / world_size {world_size} / num_ranks_per_node {num_ranks_per_node}")
+
+
+class MscclppCommunicator:
+    @staticmethod
+    def createUniqueId():
+        """A picklable token (rank 0 broadcasts it with broadcast_object_list): 16 random bytes as a hex string."""
+        return os.urandom(16).hex()
+
+    def __init__(self, unique_id, params, group=None):
+        if not isinstance(unique_id, str) or len(unique_id) != 32:
+            raise ValueError("MscclppCommunicator: unique_id must come from MscclppCommunicator.createUniqueId()")
+        self.unique_id, self.params = unique_id, params
+        # the world group of torch.distributed (the reference's `_WORLD`); resolved lazily so that a communicator may be built first
+        self._group = group
+        if dist.is_initialized():
+            if dist.get_world_size(group) != params.world_size or dist.get_rank(group) != params.rank:
+                raise RuntimeError(f"MscclppCommunicator: params (rank {params.rank} of {params.world_size}) do not match the process "
+                                   f"group (rank {dist.get_rank(group)} of {dist.get_world_size(group)})")
+        elif params.world_size != 1:
+            raise RuntimeError("MscclppCommunicator: torch.distributed must be initialised before a multi-rank communicator is built")
+        self._key = id(self)
+        _communicators[self._key] = self
+
+    @property
+    def group(self):
+        return self._group
+
+    @property
+    def rank(self):
+        return self.params.rank
+
+    @property
+    def world_size(self):
+        return self.params.world_size
+
+    def data_ptr(self):
+        return self._key
+
+    def close(self):
+        _communicators.pop(self._key, None)
+
+
+def communicator_from_ptr(comm_ptr):
+    """The MscclppCommunicator behind a `data_ptr()` value (None for the values tests / tools pass: None, 0)."""
+    if isinstance(comm_ptr, MscclppCommunicator):
+        return comm_ptr
+    if not comm_ptr:
+        return None
+    c = _communicators.get(int(comm_ptr))
+    if c is None:
+        raise RuntimeError(f"comm_ptr {comm_ptr} does not name a live MscclppCommunicator of this process")
+    return c

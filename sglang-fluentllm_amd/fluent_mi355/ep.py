@@ -113,10 +113,16 @@ class HipRowOps:
 class AllToAll:
     """AllToAll(top_k, num_experts, hidden_size, max_tokens, comm_ptr): `max_tokens` is the GLOBAL token capacity
     (low_latency_max_num_tokens_per_gpu * world, fast_ep.py:20); `comm_ptr` (MSCCL++ communicator of the reference) is
-    accepted and ignored — the exchange runs on `group` (default: the world group) of torch.distributed."""
+    the `data_ptr()` of an eps.communication.MscclppCommunicator — here a host object naming the torch.distributed group the exchange
+    runs on (`group` overrides it; default: the world group)."""
 
     def __init__(self, top_k, num_experts, hidden_size, max_tokens, comm_ptr=None, group=None, row_ops=None):
         self.top_k, self.num_experts, self.hidden = int(top_k), int(num_experts), int(hidden_size)
+        from .comm import communicator_from_ptr
+
+        self.communicator = communicator_from_ptr(comm_ptr)
+        if group is None and self.communicator is not None:
+            group = self.communicator.group
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -137,10 +143,15 @@ class AllToAll:
 
         self.oneshot = None
         self.messages = {"oneshot": 0, "rccl": 0}                 # launches per route (tests, bench `comm_route`)
+        # OPT-IN (FLUENT_EP_ONESHOT=1): the EP exchange on this transport has only ever run as several processes on ONE GPU over hipIpc
+        # (profiles/r04_ep_oneshot_two_and_three_processes_one_gpu.txt); until it has passed a real multi-GPU xGMI run the default route is
+        # RCCL all_to_all_single — a fault there is an error, not a 10 s spin followed by poisoned rows.  FLUENT_ONESHOT=0
+        # still disables every one-shot route; FLUENT_ONESHOT=1 builds the transport at world 1 as well (tests).
         want = os.environ.get("FLUENT_ONESHOT", "auto")
+        ep_optin = os.environ.get("FLUENT_EP_ONESHOT", "0") == "1"
         multi = dist.is_initialized() and self.world > 1 and dist.get_backend(group) == "nccl"
         tail = (4 * self.top_k + 7) // 8 * 8
-        if row_ops is None and want != "0" and torch.cuda.is_available() and (multi or want == "1") \
+        if row_ops is None and ep_optin and want != "0" and torch.cuda.is_available() and (multi or want == "1") \
                 and self.world * self.cap <= 1024 and self.hidden + tail <= 8192 and self.hidden % 8 == 0:
             from .oneshot import OneShotComm
             try:

@@ -255,6 +255,7 @@ def flash_mla_ckv_fp8_per_token(q_nope: torch.Tensor, q_rope: torch.Tensor, k_ca
     if softmax_scale is None:
         softmax_scale = (q_nope.shape[-1] + q_rope.shape[-1]) ** -0.5
     a = FlMlaDecodeArgs()
+    a.struct_bytes = ctypes.sizeof(FlMlaDecodeArgs)
     a.kv_format = KV_FP8_PER_TOKEN
     a.d_nope, a.d_rope = 512, 64
     a.q_nope, a.q_rope, a.q_scale = q_nope.data_ptr(), q_rope.data_ptr(), q_scale.data_ptr()
@@ -282,6 +283,7 @@ def flash_mla_ckv_fp8_per_token_bf16_q(q: torch.Tensor, k_cache_lora: torch.Tens
     if softmax_scale is None:
         softmax_scale = 576 ** -0.5
     a = FlMlaDecodeArgs()
+    a.struct_bytes = ctypes.sizeof(FlMlaDecodeArgs)
     a.kv_format = KV_FP8_PER_TOKEN
     a.d_nope, a.d_rope = 512, 64
     a.q_bf16 = q.data_ptr()
@@ -305,6 +307,7 @@ def flash_mla_with_kvcache(q: torch.Tensor, k_cache: torch.Tensor, block_table: 
     if softmax_scale is None:
         softmax_scale = q.shape[-1] ** -0.5
     a = FlMlaDecodeArgs()
+    a.struct_bytes = ctypes.sizeof(FlMlaDecodeArgs)
     a.d_nope, a.d_rope = 512, 64
     if q.dtype == torch.bfloat16:
         _req(k_cache.dtype == torch.bfloat16, "bf16 q needs a bf16 cache")

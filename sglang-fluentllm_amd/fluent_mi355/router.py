@@ -42,3 +42,61 @@ def moe_fused_gate(input_tensor, bias, num_expert_group, topk_group, topk, num_f
                                 float(routed_scaling_factor), int(bool(apply_routed_scaling_factor_on_output)), npad,
                                 w.data_ptr(), ids.data_ptr(), stream_ptr(x.device)), "fl_moe_fused_gate")
     return w, ids
+
+
+# ---- R1b: the plain top-k routers of srt/layers/moe/topk.py (csrc/moe_gate.hip: topk_gate_kernel) ----
+lib.fl_topk_gate.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                             ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+lib.fl_topk_gate.restype = ctypes.c_int
+
+
+def _topk_gate(logits, bias, topk_weights, topk_ids, score_fn, renormalize, scale, what):
+    """Runs fl_topk_gate INTO the caller's output tensors (the reference allocates them and passes them in)."""
+    if not logits.is_cuda:
+        raise RuntimeError(f"{what}: gating_output must be a CUDA/HIP tensor")
+    if logits.dim() != 2 or topk_weights.dim() != 2 or topk_weights.shape != topk_ids.shape or topk_weights.shape[0] != logits.shape[0]:
+        raise RuntimeError(f"{what}: expected gating_output [T, E] and outputs [T, topk] (got {tuple(logits.shape)}, "
+                           f"{tuple(topk_weights.shape)}, {tuple(topk_ids.shape)})")
+    if topk_weights.dtype != torch.float32 or topk_ids.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError(f"{what}: topk_weights must be float32 and topk_ids int32 / int64")
+    T, E = logits.shape
+    K = topk_weights.shape[1]
+    if T == 0:
+        return
+    x = logits.to(torch.float32).contiguous()
+    b = None if bias is None else bias.to(device=x.device, dtype=torch.float32).contiguous()
+    if b is not None and b.numel() != E:
+        raise RuntimeError(f"{what}: bias has {b.numel()} entries for {E} experts")
+    w = topk_weights if topk_weights.is_contiguous() else torch.empty(T, K, dtype=torch.float32, device=x.device)
+    ids = topk_ids if (topk_ids.dtype == torch.int32 and topk_ids.is_contiguous()) else torch.empty(T, K, dtype=torch.int32, device=x.device)
+    check(lib.fl_topk_gate(x.data_ptr(), 0 if b is None else b.data_ptr(), T, E, K, int(score_fn), int(bool(renormalize)), float(scale),
+                           w.data_ptr(), ids.data_ptr(), stream_ptr(x.device)), "fl_topk_gate")
+    if w is not topk_weights:
+        topk_weights.copy_(w)
+    if ids is not topk_ids:
+        topk_ids.copy_(ids)
+
+
+def topk_softmax(topk_weights, topk_ids, gating_output, renormalize=False):
+    """flashinfer.topk_softmax as fused_topk calls it (srt/layers/moe/topk.py:513-518): softmax over the experts in fp32, the `topk`
+    largest (descending; ties -> lower expert id), written INTO topk_weights f32 [T, topk] / topk_ids int32 [T, topk]; `renormalize`
+    divides by the sum of the chosen weights.  Torch statement: fused_topk_torch_native (:463-495)."""
+    _topk_gate(gating_output, None, topk_weights, topk_ids, 0, renormalize, 1.0, "topk_softmax")
+
+
+def topk_sigmoid(topk_weights, topk_ids, gating_output, renormalize=False, correction_bias=None):
+    """eps.utils.ops._ops.topk_sigmoid: the name srt/layers/moe/topk.py:44-47 resolves at import time (USE_EPS_TOPK_SIGMOID, default on) and
+    nothing under python/sglang calls.  The eps sources are not vendored (parity unpinned): the signature mirrors topk_softmax's —
+    sigmoid scores, optional selection bias, top-k, optional renormalisation."""
+    _topk_gate(gating_output, correction_bias, topk_weights, topk_ids, 1, renormalize, 1.0, "topk_sigmoid")
+
+
+def routing_flash(router_logits, correction_bias, topk_ids, topk_weights, num_real_experts, routed_scaling_factor=None, renormalize=False):
+    """flashinfer.routing_flash as select_experts calls it for LongCat-Flash (srt/layers/moe/topk.py:836-845): the fused form of
+    fused_topk_bias (:51-70) — softmax scores, selection by score + correction_bias, weights = the unbiased scores (x routed_scaling_factor).
+    `num_real_experts` marks the zero-computation experts (ids >= it): they are selected and weighted like any other, the MoE layer treats
+    them (models/longcat_flash.py).  The flashinfer fork's kernel is not vendored: parity is pinned on the torch statement."""
+    if correction_bias is not None and correction_bias.numel() != router_logits.shape[1]:
+        raise RuntimeError("routing_flash: correction_bias must have one entry per expert (zero experts included)")
+    _topk_gate(router_logits, correction_bias, topk_weights, topk_ids, 0, renormalize,
+               1.0 if routed_scaling_factor is None else float(routed_scaling_factor), "routing_flash")

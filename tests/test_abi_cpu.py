@@ -27,7 +27,16 @@ def test_library_exports_all_declared_symbols():
     missing = [n for n in sorted(decl) if not hasattr(lib, n)]
     assert not missing, missing
     lib.fl_version.restype = ctypes.c_int
-    assert lib.fl_version() >= 100
+    m = re.search(r"#define\s+FL_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "fluent_mi355.h")).read())
+    assert lib.fl_version() == int(m.group(1)) == 101          # header, library and the ctypes binding agree
+    from fluent_mi355 import _lib
+    assert _lib.ABI_VERSION == 101
+    # an argument struct of another layout is refused, not read past its end
+    a = _lib.FlMlaDecodeArgs()
+    a.struct_bytes = ctypes.sizeof(_lib.FlMlaDecodeArgs) - 8
+    lib.fl_mla_decode.argtypes = [ctypes.POINTER(_lib.FlMlaDecodeArgs), ctypes.c_void_p]
+    lib.fl_last_error.restype = ctypes.c_char_p
+    assert lib.fl_mla_decode(ctypes.byref(a), None) == 1 and b"struct_bytes" in lib.fl_last_error()
     lib.fl_mla_num_parts.restype = ctypes.c_int
     # 64-row workgroups for every shape (mla_decode_fp8_y.hip) -> CUs / ceil(rows / 64) parts
     assert lib.fl_mla_num_parts(256, 128) == 128
@@ -49,5 +58,4 @@ def test_shim_modules_import_and_match_reference_names():
 def test_product_path_never_imports_oracle():
     for path in glob.glob(os.path.join(PKG, "**", "*.py"), recursive=True):
         src = open(path).read()
-        assert "oracle" not in src.replace("oracle/", "").lower() or "import oracle" not in src, path
         assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), path

@@ -298,6 +298,8 @@ def test_ep_exchange_world1_oneshot_route_matches_the_plain_route(monkeypatch):
     plain = AllToAll(K, E, HID, 32, None)
     assert plain.oneshot is None
     monkeypatch.setenv("FLUENT_ONESHOT", "1")
+    assert AllToAll(K, E, HID, 32, None).oneshot is None      # the EP route on the one-shot transport is opt-in (FLUENT_EP_ONESHOT=1)
+    monkeypatch.setenv("FLUENT_EP_ONESHOT", "1")
     one = AllToAll(K, E, HID, 32, None)
     assert one.oneshot is not None and "one-shot" in one.comm_route
     o0, e0 = run(plain)

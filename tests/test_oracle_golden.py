@@ -159,6 +159,27 @@ def test_router_oracle_matches_reference_golden():
         assert_router_rows_equal(w, ids, c["w"], c["ids"], c["npad"])
 
 
+TOPK_PLAIN_CASES = ("softmax_e128", "softmax_e8", "softmax_e256", "softmax_e96", "bias_longcat", "bias_e64")
+
+
+def topk_plain_case(g, name):
+    K, renorm = (int(v) for v in g[name + "_cfg"])
+    return dict(logits=g[name + "_logits"], bias=g[name + "_bias"] if name + "_bias" in g.files else None, K=K, renorm=bool(renorm),
+                w=g[name + "_w"], ids=g[name + "_ids"])
+
+
+def test_plain_topk_router_oracle_matches_reference_golden():
+    """oracle.router_ref.topk_plain ≡ the reference's fused_topk_native (moe/topk.py:73-91, behind flashinfer.topk_softmax) and
+    fused_topk_bias (:51-70, behind flashinfer.routing_flash) run from their own source: same expert sets, weights within 2e-6."""
+    from oracle import router_ref
+
+    g = load_golden("router_topk_plain.npz")
+    for name in TOPK_PLAIN_CASES:
+        c = topk_plain_case(g, name)
+        w, ids = router_ref.topk_plain(c["logits"], c["K"], c["renorm"], c["bias"])
+        assert_router_rows_equal(w, ids, c["w"], c["ids"], None)
+
+
 def test_rope_oracle_bit_exact_vs_reference_golden():
     """oracle.rope_ref.apply_rope ≡ DeepseekScalingRotaryEmbedding.forward_native (rotary_embedding.py:804-846) run from the
     reference's own source with its YaRN fp32 cache: bf16 bits identical, GPT-J and NeoX styles."""

@@ -10,8 +10,10 @@ import flash_mla_fp8 as fm
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 H = int(sys.argv[3]) if len(sys.argv) > 3 else bench.H
+bs = int(sys.argv[4]) if len(sys.argv) > 4 else bench.BS
+seq = int(sys.argv[5]) if len(sys.argv) > 5 else bench.SEQ
 dev = torch.device("cuda:0")
-wl = bench.build_workload(dev, layers, bench.BS, bench.SEQ, H, seed=1)
+wl = bench.build_workload(dev, layers, bs, seq, H, seed=1)
 meta, ns = fm.get_mla_metadata(wl["seqlens"], H, 1)
 qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
 pages = wl["pages"]

@@ -15,6 +15,8 @@ if os.environ.get("SHARE_PAGES"):   # experiment: every request reads request 0'
     wl["block_table"] = wl["block_table"][torch.arange(bs, device=dev) // k * k].contiguous()
 if os.environ.get("SEQ_PAGES"):    # experiment: pages in address order instead of randomly permuted (TLB / DRAM locality)
     wl["block_table"] = (torch.arange(bs * (seq // 64), device=dev, dtype=torch.int32) + 1).view(bs, -1).contiguous()
+if os.environ.get("QSCALE"):   # experiment: logits QSCALE x wider (a later block's reference far above the first block's: the O-reference lift / redo pass)
+    wl["q"] = (wl["q"].float() * float(os.environ["QSCALE"])).to(torch.bfloat16)
 meta, ns = fm.get_mla_metadata(wl["seqlens"], H, 1)
 qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
 pages = wl["pages"]
