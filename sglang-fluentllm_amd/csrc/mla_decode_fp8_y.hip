@@ -36,8 +36,7 @@ constexpr int kOffRef = kOffPbuf + 2 * kPbufPerParity;             // [parity 2]
 constexpr int kScratchPerWave = 2 * 3 * 32 * 4;                    // [page parity 2] {ks, log2 ks, 1/ks} x 32 tokens
 constexpr int kOffScratch = kOffRef + 2 * kRefPerParity;           // [QK wave 4]
 constexpr int kOffLm = kOffScratch + 4 * kScratchPerWave;          // [rt 2][W 2][3][32] f32: l, lq, m per row
-constexpr int kOffFlag = kOffLm + 2 * 2 * 3 * 32 * 4;              // 4 ints: redo votes of the PV waves
-constexpr int kOffQr = kOffFlag + 16;                                 // [QK wave 4][4 k-steps][64 lanes] 16 B: Q rope fragments
+constexpr int kOffQr = kOffLm + 2 * 2 * 3 * 32 * 4;                   // [QK wave 4][4 k-steps][64 lanes] 16 B: Q rope fragments
 constexpr int kOffMerge = kOffQr + 4 * 4096;                            // 1 int: PV waves of this workgroup past a merge's poll (in-kernel split merge)
 constexpr int kLdsBytes = kOffMerge + 16;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
@@ -272,20 +271,17 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
 }
 
 // ---- PV wave: O^T[256 dims x 32 rows] += V^T(page) . P^T, with the LDS-DMA refill of a later page in the MFMA shadow ----
-// The reference of O is fixed when a row sees its first valid token and NEVER moves in a pass: later blocks with a larger
-// reference m_b enter with an E8M0 block scale 2^(m_b - m_o) > 1 (exact; fp32 O has the range), so nothing but the MFMA
-// touches O in the page loop (a conditional rescale makes hipcc copy all 128 O registers at the join, every page).  Only
-// a reference more than kMaxUp above m_o cannot be represented: it raises `redo` and the workgroup repeats the request
-// with m_o preset to the final reference.
-// The reference is set kRefLift ABOVE the first block's (a power-of-two rescale of O: exact, fp32 has the range both ways), so that
-// a later block may exceed the first by kRefLift + kMaxUp = 128 log2 units (89 nats) before the pass is repeated: with the
-// first block's own reference (round 2-4) any logit spread beyond 2^64 between a row's first block and its maximum doubled the
-// request's time (seen at BASELINE config 4 with random projection weights: 0.87 instead of 0.47 ms per launch).
-// Overflow bound: |O| <= 2^6 (P') x 2^9 (fp8 V) x 2^17 tokens x 2^kMaxUp = 2^120.
+// The reference of O is fixed when a row sees its first valid token, kRefLift ABOVE that block's reference (a power-of-two offset: exact,
+// fp32 has the range both ways): later blocks with a larger reference m_b enter with an E8M0 block scale 2^(m_b - m_o) > 1 (exact), so nothing
+// but the MFMA touches O in the page loop.  A later block may exceed the first by kRefLift + kMaxUp = 128 log2 units (89 nats) that way;
+// beyond that (never seen on model data; synthetic projection weights do it) the row's reference moves up IN PLACE, in an out-of-line
+// block of the step: O *= 2^(m_o - m_new).  (Rounds 2-4 repeated the whole request with the final reference instead — a `redo` pass that
+// doubled the request's time whenever a row's logits spread over more than 2^64: 0.87 instead of 0.47 ms per launch at BASELINE config 4
+// with random projection weights.)  Overflow bound: |O| <= 2^6 (P') x 2^9 (fp8 V) x 2^17 tokens x 2^kMaxUp = 2^120.
 constexpr float kMaxUp = 88.f;
 constexpr float kRefLift = 40.f;
 template <bool DMA, int FMT>
-__device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, const PvLane& lc_in, const int lane,
+__device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, const PvLane& lc_in, const int lane,
                                         const uint8_t* __restrict__ vp, const uint8_t* __restrict__ pbuf_rt,
                                         const float* __restrict__ ref_rt, const uint8_t* __restrict__ src_nope,
                                         uint8_t* __restrict__ dma_dst FL_T_PARAMS) {
@@ -313,7 +309,18 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, int& redo, con
   load_vt(2);
   const float mw_max = fmaxf(m0, m1);
   m_o = m_o > kNegRef ? m_o : (mw_max > kNegRef ? mw_max + kRefLift : kNegRef);
-  redo |= (mw_max - m_o > kMaxUp) ? 1 : 0;
+  if (__builtin_expect(__any(mw_max - m_o > kMaxUp), 0)) {
+    // a block reference outran the O reference by more than kMaxUp: move this row's reference up IN PLACE — O *= 2^(m_o - m_new), exact in
+    // fp32 down to the subnormals, which lie 2^-100 below the row's new maximum (hipcc keeps the 128 multiplies out of line: no copy of O on
+    // the common path)
+    const float m_up = mw_max - m_o > kMaxUp ? mw_max + kRefLift : m_o;
+    const float f_up = __builtin_amdgcn_exp2f(m_o - m_up);   // exactly 1 for the lanes whose row did not jump
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[j][r] *= f_up;
+    m_o = m_up;
+  }
   int sb = 127 + (int)fminf((lh ? m1 : m0) - m_o, kMaxUp);
   sb = sb < 0 ? 0 : sb;
   const v8i pb = make_v8i(p0, p1);
@@ -493,8 +500,6 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
   load_window(0);                                                                                                      \
   auto page_of = [&](int t) { return (long long)__builtin_amdgcn_readlane(pg_vec, t - win_base); }
 
-  const int* redo_flag = reinterpret_cast<const int*>(smem + kOffFlag);
-
   if (!is_pv) {
     // =========================== QK waves ===========================
     QkLane lc;
@@ -619,17 +624,16 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
           r.ks = *scale_src(t);
         }
       };
-      for (int pass = 0; pass < 2; ++pass) {
+      {
         float l_run = 0.f, lq_run = 0.f, m_w = kNegRef;
         RopeRegs rA, rB;
-        if (pass == 1) load_window(0);
         load_rope(rA, 0);
         load_rope(rB, n > 1 ? 1 : 0);
         if constexpr (FMT == 0)
           scale_prep(scratch, rA.ks, tile_b * kPage + 32 * W, li, L);   // page 0 -> parity 0 (this wave's reads of the previous request are done)
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // R0: every wave is done with the LDS of the previous request / pass
+        __builtin_amdgcn_s_barrier();   // R0: every wave is done with the LDS of the previous request
         FL_T(5);   // request prologue
 
         // step i uses `rr` (page i) and refills it with page i+2; `rn` holds page i+1
@@ -689,8 +693,6 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // E0
         FL_T(4);   // B_n, normalisers, E0
-        if (pass == 1) break;
-        if ((redo_flag[0] | redo_flag[1] | redo_flag[2] | redo_flag[3]) == 0) break;   // workgroup-uniform
       }
     }
 #ifdef FL_MLA_TIMING
@@ -741,19 +743,14 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
 
     v16f o[8];
     float m_o = kNegRef;
-    float mo_preset = kNegRef;
-    // pass 0 fixes the O reference at each row's first valid page; pass 1 runs only if some block reference outran it
-    // by more than kMaxUp (pv_step), with the reference preset to the final one
-    for (int pass = 0; pass < 2; ++pass) {
+    {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
-      m_o = mo_preset;
-      int redo = 0;
-      if (pass == 1) load_window(0);
+      m_o = kNegRef;
 
-      if (first_item && pass == 0) {
+      if (first_item) {
         // the workgroup's first request: nobody has touched the ring yet — the first two pages go out as soon as their ids are
         // here, not behind the QK waves' rope / scale loads (R0): one memory round trip less in the start-up chain
         if (n > 0) issue_page(0);
@@ -786,7 +783,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const uint8_t* sn = HAS_DMA ? src_of(i + 2) : nullptr;                                                             \
     uint8_t* dst = ring(i + 2) + w4 * (kPiecesPerWave * 1024);                                                         \
     if (HAS_PREV) {                                                                                                    \
-      pv_step<HAS_DMA, FMT>(o, m_o, redo, lc, lane, ring(i - 1) + W * 256,                                                  \
+      pv_step<HAS_DMA, FMT>(o, m_o, lc, lane, ring(i - 1) + W * 256,                                                  \
                        smem + kOffPbuf + ((i - 1) & 1) * kPbufPerParity + rt * (2 * 64 * 16),                          \
                        reinterpret_cast<const float*>(smem + kOffRef + ((i - 1) & 1) * kRefPerParity) + rt * 64, sn,   \
                        dst FL_T_ARGS);                                                                                 \
@@ -813,14 +810,9 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
         for (; i <= n; ++i) FL_Y_PV_STEP(true, false)
       }
 #undef FL_Y_PV_STEP
-      // workgroup-uniform redo decision (the page loop has workgroup barriers)
-      if (lane == 0) reinterpret_cast<int*>(smem + kOffFlag)[w4] = (pass == 0 && __any(redo != 0)) ? 1 : 0;
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // E0: normalisers of the QK waves and the redo votes are in LDS, the ring is free
+      __builtin_amdgcn_s_barrier();   // E0: the normalisers of the QK waves are in LDS, the ring is free
       FL_T(3);   // E0
-      if (pass == 1) break;
-      if ((redo_flag[0] | redo_flag[1] | redo_flag[2] | redo_flag[3]) == 0) break;
-      mo_preset = fmaxf(lm[64 + li], lm[96 + 64 + li]);   // final references of the two blocks
     }
 
     // ---- per-request epilogue: merge the normalisers of the two blocks, normalise, store this wave's d half ----
