@@ -149,7 +149,7 @@ def k1_ragged_variant(dev, layers=61):
 def kernel_variants(dev, n_caches=16, launches=64):
     """The other decode kernels of the path at the cfg2 batch (bs=128, seq=4096), measured like the headline's K1 (one hipGraph of `launches`
     launches cycling over `n_caches` distinct caches = 5.4 GB and more: nothing is re-served from the 256 MB Infinity Cache; HIP events on the
-    launch stream): cfg2_h16 = K1 for the TP8 shard (H=16, mla_decode_fp8_kernel<1>: BASELINE.md section 4 row 2), k2_fp8 / k2_bf16 =
+    launch stream): cfg2_h16 = K1 for the TP8 shard (H=16: BASELINE.md section 4 row 2), k2_fp8 / k2_bf16 =
     flash_mla_with_kvcache over a plain fp8 / bf16 [.,576] cache (flashmla_backend.py:163-175,227-254)."""
     import flash_mla_fp8 as fm
     import flash_mla_swap as fsw
@@ -201,8 +201,8 @@ def kernel_variants(dev, n_caches=16, launches=64):
             k_lora, k_scale, k_rope = wl["caches"][l]
             fm.flash_mla_ckv_fp8_per_token(qn, qr, k_lora.view(pg, 64, 1, 512), k_rope.view(pg, 64, 1, 64), qs, k_scale.view(pg, 64, 1, 1),
                                            wl["block_table"], wl["seqlens"], 512, meta, ns, SCALE, True)
-        record("cfg2_h16", "cfg2 TP8 shard: bs=128 seq=4096 H=16, per-token fp8 KV, K1 only (+ its split combine)", timed(k1),
-               algorithmic_bytes(BS, SEQ, h, 1), kernel="mla_decode_fp8_kernel<1,0> + mla_combine_kernel", parts=int(meta.shape[0]),
+        record("cfg2_h16", "cfg2 TP8 shard: bs=128 seq=4096 H=16, per-token fp8 KV, K1 only", timed(k1),
+               algorithmic_bytes(BS, SEQ, h, 1), kernel="mla_decode_y_kernel<0,false,1> (4-wave instantiation; split requests merged inside the kernel)", parts=int(meta.shape[0]),
                splits=int(ns[-1]) - BS)
         del wl
     except Exception as ex_:
@@ -774,7 +774,7 @@ def main():
         # WRITE_SIZE, MI355X_MICROARCH.md) of the kernel this build dispatches at this workload; the source file is named
         traffic, traffic_src = None, None
         try:
-            traffic_src = "profiles/r04_pmc_traffic.json"
+            traffic_src = "profiles/r05_pmc_traffic.json"
             with open(os.path.join(ROOT, traffic_src)) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch"])
         except Exception:

@@ -232,7 +232,7 @@ int fl_comm_workspace_size(int world, int64_t max_tokens, int hidden, int64_t* b
 int fl_comm_create(int rank, int world, int64_t max_tokens /*<= 1024*/, int hidden /*<= 8192*/, void** comm_out);
 int fl_comm_local_handle(void* comm, void* handle_out /*64 bytes: hipIpcMemHandle_t of this rank's workspace*/);
 int fl_comm_connect(void* comm, const void* handles /*world x 64 bytes in rank order; NULL allowed at world 1*/);
-int fl_comm_set_timeout(void* comm, double seconds /*budget of one flag wait; default 2 s*/);
+int fl_comm_set_timeout(void* comm, double seconds /*budget of one flag wait; default 10 s*/);
 /* C5: all ranks pass in bf16 [T, H]; every rank gets sum (+ residual_in [T, H]) -> residual_out, RMSNorm -> norm_out,
  * quant_out/scale_out optional (any may be NULL; gamma NULL = sum only into residual_out). */
 int fl_allreduce_fused(void* comm, const void* in, int64_t T, int H, const void* residual_in, const void* gamma, float eps,

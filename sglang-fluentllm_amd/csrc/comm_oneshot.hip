@@ -414,7 +414,7 @@ extern "C" int fl_comm_create(int rank, int world, int64_t max_tokens, int hidde
   c->world = world;
   c->L = FlCommLayout{world, max_tokens, hidden};
   c->connected = false;
-  c->timeout_s = 120.0;
+  c->timeout_s = 10.0;   // budget of ONE flag wait (a healthy exchange takes microseconds); FLUENT_ONESHOT_TIMEOUT_S / fl_comm_set_timeout change it
   c->host_err = c->host_err_dev = nullptr;
   for (int p = 0; p < kMaxWorld; ++p) { c->peer[p] = nullptr; c->opened[p] = false; }
   {

@@ -58,7 +58,7 @@ __device__ __forceinline__ void kblock_body(v16f (&acc)[MT], const uint8_t* __re
                                             const uint8_t* const (&src_a)[MT],
                                             const float* const (&src_as)[Smem<MT>::kAsFloats / 64], const long long k_off,
                                             const long long as_off, const bool issue, const bool more_in_flight,
-                                            const float ws, const int (&rb)[4], const int wave, const int li) {
+                                            const float ws, const int (&rb)[4], const int wave, const int li, const bool w_nt) {
   constexpr int kAsPieces = Smem<MT>::kAsFloats / 64;
   // ---- stage kb landed for every wave; stages kb+1, kb+2 (issued later) may stay in flight ----
   if (more_in_flight) {   // leave the (kStages - 2) later stages in flight
@@ -75,7 +75,7 @@ __device__ __forceinline__ void kblock_body(v16f (&acc)[MT], const uint8_t* __re
   if (issue) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)   // W: 16 pieces of 8 rows x 128 B; this wave fills pieces 4*wave + k
-      fl_dma16(src_w[k] + k_off, dma_w + (wave * 4 + k) * 1024);
+      fl_dma16_pol(src_w[k] + k_off, dma_w + (wave * 4 + k) * 1024, w_nt);
 #pragma unroll
     for (int k = 0; k < MT; ++k)  // A: 4*MT pieces; this wave fills pieces wave*MT + k
       fl_dma16(src_a[k] + k_off, dma_a + (wave * MT + k) * 1024);
@@ -133,6 +133,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const uint8_t* __
   long long row_end = 0;  // one past the last valid row
   if (!locate_tile<BM>(p, gmeta, mt, e, row0, row_end)) return;
   const int n0 = nt * BN;
+  // The weight panel of this tile is streamed ONCE by ONE workgroup when its group fits one token tile; in the decode regime proper — at most 16 rows
+  // per group — the non-temporal policy on it is worth +7...11 % of weight bandwidth (MI355X guide, "nt-weights"; measured 4 / 8 / 16 rows per expert:
+  // 6.20 -> 6.86, 6.15 -> 6.83, 5.95 -> 6.49 TB/s), at 32 rows per expert and on the dense GEMMs at T >= 128 it costs 3-4 % (the token rows that every
+  // weight tile of the group re-reads compete with the stream): profiles/r05_nt_policy.txt.  (Also true for a short LAST tile of a longer group.)
+  const bool w_nt = row_end - row0 <= 16;
   const int KB_all = p.K / BK;
   const int kb_per = (KB_all + p.ksplit - 1) / p.ksplit;
   const int kb0 = split * kb_per;
@@ -192,7 +197,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const uint8_t* __
     const int st = kb % kStages;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      fl_dma16(wsrc[k] + (long long)kb * BK, stage_w(st) + (wave * 4 + k) * 1024);
+      fl_dma16_pol(wsrc[k] + (long long)kb * BK, stage_w(st) + (wave * 4 + k) * 1024, w_nt);
 #pragma unroll
     for (int k = 0; k < MT; ++k)
       fl_dma16(asrc[k] + (long long)kb * BK, stage_a(st) + (wave * MT + k) * 1024);
@@ -213,7 +218,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const uint8_t* __
     const int nst = (kb + kStages - 1) % kStages;
     kblock_body<MT>(acc, stage_w(st), stage_a(st), stage_as(st), stage_w(nst), stage_a(nst), stage_as(nst), wsrc, asrc,
                     assrc, (long long)(kb + kStages - 1) * BK, (long long)(kb + kStages - 1) * p.as_stride_k,
-                    kb + kStages - 1 < KB, kb + kStages - 2 < KB, wsrow[kb], rb, wave, li);
+                    kb + kStages - 1 < KB, kb + kStages - 2 < KB, wsrow[kb], rb, wave, li, w_nt);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

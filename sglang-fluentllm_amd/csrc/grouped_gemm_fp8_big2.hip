@@ -17,8 +17,7 @@
 //     run half a step apart, separated by workgroup barriers: while one wave of a SIMD issues its 8 MFMAs (segment M),
 //     its partner issues LDS-DMA, reads operands and rescales (segment L).  Intervals:
 //         X:  L0 | M0 | L1 | M1 | ...            (a barrier between all segments; Y executes one barrier more
-//         Y:     | L0 | M0 | L1 | M1 | ...        up front, X one more at the end.  FL_GEMM2_ONEBAR=1 (experiment, slower): only the
-//                                                 barriers in front of X's L segments — X runs L(h) M(h), Y runs M(h-1) L(h) per step)
+//         Y:     | L0 | M0 | L1 | M1 | ...        up front, X one more at the end)
 //   * XCD-aware tile order: the 32 workgroups of an XCD in one round take 32 CONSECUTIVE tiles (n fastest): the tiles of
 //     one 512-row expert (2 x 16 tiles of w13) share their W and A panels through ONE L2.
 #include "grouped_gemm_shared.h"
@@ -58,29 +57,10 @@ __device__ __forceinline__ void mfma_acc(v16f& acc, const v8i a, const v8i b, co
                : "v"(a), "v"(b), "v"(kUnit), "v"(sb));
 }
 
-#ifndef FL_GEMM2_PKMUL
-#define FL_GEMM2_PKMUL 0
-#endif
-#ifndef FL_GEMM2_DMA_LODD
-#define FL_GEMM2_DMA_LODD 0   // experiment: the pieces of stage h + 3 for EVEN h are issued in the (light) L segment of step h + 1
-                              // instead of behind the MFMAs of step h, whose M segment also carries 64 rescale multiplies
-#endif
-#ifndef FL_GEMM2_YPRIO
-#define FL_GEMM2_YPRIO 0      // experiment: static priority 1 for group Y (waves 4-7: the younger half loses the arbitration)
-#endif
-#ifndef FL_GEMM2_XTILE
-#define FL_GEMM2_XTILE 1      // the refill crosses tile boundaries (0: every tile starts with a cold three-stage prologue).  Measured
-                              // (profiles/r03_gemm_big2_xtile_ab.txt): w13 -0.4 %, w2 +1.4 % — the kernel is power-capped; kept for the
-                              // short-k shapes (w2: 16 k blocks per tile) and because this form allocates without scratch (the 0 form: 8 B)
-#endif
-#ifndef FL_GEMM2_ONEBAR
-#define FL_GEMM2_ONEBAR 0     // experiment (parity-green, measured SLOWER: w13 -2.5 %, w2 -3.5 %, profiles/r03_gemm_big2_onebar_ab.txt): ONE
-                              // barrier per half step — the barrier between a step's two intervals (X: L | M, Y: M | L) dropped; nothing
-                              // is handed over there, but without it the two groups' M segments overlap in time and the step gets longer
-#endif
-#ifndef FL_GEMM2_PRIO
-#define FL_GEMM2_PRIO 0   // measured (profiles/r03_gemm_big2_variants_ab.txt): +2 % without the priority flips
-#endif
+// (The experiment switches of rounds 3-4 — packed rescale multiplies, refill pieces in the odd L segments, static priority for the younger
+//  wave group, one barrier per half step, priority flips around the M segment, tile-local refill — live in
+//  probes/r05_gemm_big2_lab_switches.patch.txt with their measured results: profiles/r03_gemm_big2_*.txt, profiles/r04_gemm_big2_bounding_ladder.txt.
+//  The refill crosses tile boundaries: the stages in flight past the end of a tile belong to the next one.)
 #define G2_BARRIER()                          \
   do {                                        \
     __builtin_amdgcn_sched_barrier(0);        \
@@ -154,7 +134,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
 
   // ---- PERSISTENT tile walk: the launch has one workgroup per CU (135 KiB of LDS: one fits); workgroup b takes the slots
   //      b, b + grid, b + 2 grid, ... of the tile list.  Between two tiles of a workgroup nothing is torn down, and
-  //      (FL_GEMM2_XTILE) the refill runs ACROSS tiles: the three stages that are in flight past the end of a tile are the
+  //      the refill runs ACROSS tiles: the three stages that are in flight past the end of a tile are the
   //      next tile's stages 0..2, the barrier that ends the tile is the next tile's first, and the next tile's lookup
   //      is done while its first stages fly.  XCD-aware order (speed only): slot s runs on XCD s % 8 (grid % 8 == 0); within
   //      a round of 256 slots XCD x takes the logical tiles [32x, 32x + 32) of the round (n fastest: the 2 x 16 tiles of a
@@ -179,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   int nslot = slot + gridDim.x;
   for (; nslot < p.total_blocks; nslot += gridDim.x)
     if (setup_tile(nslot, nxt)) { has_next = true; break; }
-  const bool xt = FL_GEMM2_XTILE && has_next;   // the stages past the end of this tile belong to `nxt`
+  const bool xt = has_next;   // the stages past the end of this tile belong to `nxt`
   const int e = cur.e, n0 = cur.n0;
   const long long row0 = cur.row0, row_end = cur.row_end;
 
@@ -239,10 +219,6 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   //      four L waves of an interval would queue 18 pieces behind each other at the CU's vector-memory path (measured:
   //      L segments of ~810 cycles, the slowest wave of a group sets the interval) — the refill rides behind the MFMAs ----
   auto seg_load = [&](const int h, const bool even, const bool first_kb) {
-    if (FL_GEMM2_DMA_LODD && !even) {   // stage (h - 1) + 3 of the previous, even step
-#pragma unroll
-      for (int k = 0; k < 4; ++k) issue_piece(h + 2, k);
-    }
     const uint8_t* sw = smem + ((gb + h) & (kSlots - 1)) * kSlot + (64 * wn) * BKH;
     const uint8_t* sa = smem + ((gb + h) & (kSlots - 1)) * kSlot + kWHalf + (128 * wm) * BKH;
     wa[0] = ld8(sw);
@@ -273,20 +249,8 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
         for (int j = 2; j < 4; ++j)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-#if FL_GEMM2_PKMUL   // experiment: packed f32 multiplies in the L segment (this wave has no MFMA in flight here)
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            const v2f r2 = {ratio[j], ratio[j]};
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-              v2f x = {acc[i][j][2 * r], acc[i][j][2 * r + 1]};
-              asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x) : "v"(r2));
-              acc[i][j][2 * r] = x[0];
-              acc[i][j][2 * r + 1] = x[1];
-            }
-#else
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] *= ratio[j];
-#endif
             asm volatile("" : "+v"(acc[i][j]));
           }
       }
@@ -296,13 +260,12 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
   //      MFMA each (the piece's issue stall hides under the 64 cycles of the MFMA in the pipe).  First half of a k block:
   //      the rescale of blocks 0, 1 rides behind the first four MFMAs, the pieces behind the last four ----
   auto seg_mma = [&](const int h, const bool even, const bool first_kb) {
-    if (FL_GEMM2_PRIO) __builtin_amdgcn_s_setprio(1);
     if (even && first_kb) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int j = (2 + (t >> 1)) & 3, i = t & 1;
         mfma_zero(acc[i][j], wa[i], tb[j], e8[j]);
-        if (t >= 4 && !FL_GEMM2_DMA_LODD) issue_piece(h + 3, t - 4);
+        if (t >= 4) issue_piece(h + 3, t - 4);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -324,12 +287,11 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
       for (int t = 0; t < 4; ++t) {
         const int j = t >> 1, i = t & 1;
         mfma_acc(acc[i][j], wa[i], tb[j], e8[j]);
-        if (even) { if (!FL_GEMM2_DMA_LODD) issue_piece(h + 3, t); }
+        if (even) issue_piece(h + 3, t);
         else if (t == 0) issue_piece(h + 3, 4);   // (h odd: stage h + 3 is even — it carries the scales)
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (FL_GEMM2_PRIO) __builtin_amdgcn_s_setprio(0);
   };
 
 #ifdef FL_GEMM2_TIMING
@@ -359,26 +321,24 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     GT(0);
     // (k block 0 keeps this barrier: its M segment issues stage 3 into the slot that was the PREVIOUS tile's epilogue staging area,
     //  and group Y passes this barrier only after its own epilogue)
-    if (!FL_GEMM2_ONEBAR || first) G2_BARRIER();
+    G2_BARRIER();
     GT(3);
     seg_mma(h, true, first);
     GT(1);
-    // (FL_GEMM2_DMA_LODD: stage h + 3 has not been issued yet — it goes out in the L segment below: only stage h + 2 stays in flight)
-    if (FL_GEMM2_DMA_LODD) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     GT(2);
     G2_BARRIER();
     GT(3);
     seg_load(h + 1, false, false);
     GT(0);
-    if (!FL_GEMM2_ONEBAR) G2_BARRIER();
+    G2_BARRIER();
     GT(3);
     seg_mma(h + 1, false, false);
   };
   auto kblock_y = [&](const int kb, const bool first) __attribute__((always_inline)) {
     const int h = 2 * kb;
     GT(1);
-    if (!FL_GEMM2_ONEBAR || first) G2_BARRIER();
+    G2_BARRIER();
     GT(3);
     seg_load(h, true, first);
     // reads of slot h complete (group X refills it right after the next barrier) + this wave's pieces of stage h + 1:
@@ -391,7 +351,7 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     GT(3);
     seg_mma(h, true, first);
     GT(1);
-    if (!FL_GEMM2_ONEBAR) G2_BARRIER();
+    G2_BARRIER();
     GT(3);
     seg_load(h + 1, false, false);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -414,7 +374,6 @@ __global__ __launch_bounds__(512, 1) void grouped_gemm_fp8_big2_kernel(const Gem
     if (xt) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     G2_BARRIER();   // (group Y's last M segment starts here)
   } else {         // ---------------- group Y: the same stream, one segment later ----------------
-    if (FL_GEMM2_YPRIO) __builtin_amdgcn_s_setprio(1);
     if (!carried) {   // (carried: group Y's wait at the end of the previous tile's last L segment was for this stage)
       asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
       G2_BARRIER();

@@ -43,7 +43,10 @@ static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 constexpr int kStgBytes = 512 + 16;                                // epilogue staging: bytes per row (256 bf16 dims of a PV wave + pad; in the ring)
 static_assert(4 * 32 * kStgBytes <= kRingSlots * kSlotBytes, "epilogue staging fits the ring");
 
-constexpr int kPiecesPerWave = kDmaNopePerTile / 4;                // 8 LDS-DMA pieces of 1 KiB per PV wave and page
+// NRT = row tiles of 32 query rows per workgroup: 2 (64 rows, 8 waves: two per SIMD) for more than 32 rows per request; 1 (32 rows, 4
+// waves: q(W), v(Wd), one per SIMD) for at most 32 rows — the TP8 shard's H = 16.  The 32 LDS-DMA pieces of a page are shared by the
+// 2 NRT PV waves: 8 or 16 pieces of 1 KiB per PV wave and page.
+template <int NRT> constexpr int pieces_per_wave() { return kDmaNopePerTile / (2 * NRT); }
 constexpr unsigned long long kMergeTimeoutTicks = 200000000ull;    // 2 s of the 100 MHz wall clock: budget of the in-kernel split merge's poll
 
 // (The experiment switches of rounds 2-4 — mid-step barrier, dual accumulate chain, lagged reference, tail loads inside the chain,
@@ -80,7 +83,7 @@ struct PvLane {
 //  is the same 512-B-row slot: only the latent part of a row is staged, the row's rope bytes go to registers)
 template <int FMT>
 __device__ __forceinline__ unsigned dn_off(const PvLane& lc, const int k) {
-  return lc.dn_row + (unsigned)k * (FMT == 1 ? 1152u : 1024u) + (lc.dn_x ^ ((unsigned)k << 5));
+  return lc.dn_row + (unsigned)k * (FMT == 1 ? 1152u : 1024u) + (lc.dn_x ^ ((unsigned)(k & 7) << 5));
 }
 
 __device__ __forceinline__ float fl_max3(const float a, const float b, const float c) {
@@ -280,7 +283,7 @@ __device__ __forceinline__ void qk_step(float& l_run, float& lq_run, float& m_w,
 // with random projection weights.)  Overflow bound: |O| <= 2^6 (P') x 2^9 (fp8 V) x 2^17 tokens x 2^kMaxUp = 2^120.
 constexpr float kMaxUp = 88.f;
 constexpr float kRefLift = 40.f;
-template <bool DMA, int FMT>
+template <bool DMA, int FMT, int NRT, bool NT>
 __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, const PvLane& lc_in, const int lane,
                                         const uint8_t* __restrict__ vp, const uint8_t* __restrict__ pbuf_rt,
                                         const float* __restrict__ ref_rt, const uint8_t* __restrict__ src_nope,
@@ -328,7 +331,11 @@ __device__ __forceinline__ void pv_step(v16f (&o)[8], float& m_o, const PvLane& 
   for (int jb = 0; jb < 8; ++jb) {
     if (jb + 3 < 8) load_vt(jb + 3);
     o[jb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va[jb], pb, o[jb], 0, 0, 0, kUnitScale, 0, sb);
-    if (DMA) fl_dma16_s(src_nope, dn_off<FMT>(lc, jb), dma_dst + jb * 1024);
+    if (DMA) {
+      constexpr int kPer = pieces_per_wave<NRT>() / 8;   // refill pieces behind each PV MFMA: 1 (NRT = 2) or 2
+#pragma unroll
+      for (int k = jb * kPer; k < (jb + 1) * kPer; ++k) fl_dma16_s_nt<NT>(src_nope, dn_off<FMT>(lc, k), dma_dst + k * 1024);
+    }
   }
   // V^T operand reads three tiles ahead of their MFMA
   __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
@@ -430,9 +437,12 @@ __device__ __forceinline__ void qk_step1(float& l_run, float& lq_run, float& m_w
   }
 }
 
-template <int FMT, bool QBF = false>   // QBF: the query arrives unquantised (bf16) and K4 runs in the QK waves' request prologue
-
-__global__ __launch_bounds__(512) void mla_decode_y_kernel(
+// QBF: the query arrives unquantised (bf16) and K4 runs in the QK waves' request prologue.  NT: the latent pages go through the LDS-DMA with the
+// non-temporal policy — for launches in which ONE workgroup reads a page (one row group per request: H <= 64 at s_q = 1): measured -6.4 % at H = 64,
+// -8 % at H = 16; with two row groups per request (H = 128) the second reader loses part of its L2 hits (HBM traffic 1.09 x instead of 1.006 x
+// algorithmic, +-1 % in time): default policy there (profiles/r05_nt_policy.txt)
+template <int FMT, bool QBF = false, int NRT = 2, bool NT = false>
+__global__ __launch_bounds__(256 * NRT) void mla_decode_y_kernel(
     const Params p, const int32_t* __restrict__ g_block_table, const int32_t* __restrict__ g_seqlens,
     const int32_t* __restrict__ g_meta, int32_t* g_merge_ctr, const int32_t* __restrict__ g_num_splits,
     const uint8_t* __restrict__ g_k_nope, const uint16_t* __restrict__ g_k_rope, const float* __restrict__ g_k_scale,
@@ -441,10 +451,12 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
 
   const int tid = threadIdx.x;
   const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_pv = wave_id >= 4;
-  const int w4 = wave_id & 3;
-  const int rt = w4 & 1;    // row tile (32 query rows) inside the workgroup
-  const int W = w4 >> 1;    // QK wave: token half; PV wave: d half
+  constexpr int kRoleWaves = 2 * NRT;                      // QK waves = PV waves = 2 per row tile
+  constexpr int kPiecesPerWave = pieces_per_wave<NRT>();
+  const bool is_pv = wave_id >= kRoleWaves;
+  const int w4 = is_pv ? wave_id - kRoleWaves : wave_id;   // index of the wave inside its role
+  const int rt = NRT == 2 ? (w4 & 1) : 0;                  // row tile (32 query rows) inside the workgroup
+  const int W = NRT == 2 ? (w4 >> 1) : w4;                 // QK wave: token half; PV wave: d half
   const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
 
   // ---- workgroup -> (part, row group); the row groups of a part read the same pages: same XCD (block b -> XCD b%8) ----
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
   const int end_tile = meta[3];
   int split_idx = meta[4];
 
-  const int row = rgrp * 64 + rt * 32 + li;   // query row of this lane (both roles: lane&31 = row inside the tile)
+  const int row = rgrp * (32 * NRT) + rt * 32 + li;   // query row of this lane (both roles: lane&31 = row inside the tile)
   const bool row_ok = row < p.rows;
 
 #ifdef FL_MLA_TIMING
@@ -720,7 +732,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     lc.dn_x = (unsigned)((li ^ lh) << 4);
   }
   int* msync = reinterpret_cast<int*>(smem + kOffMerge);
-  if (wave_id == 4 && lane == 0) msync[0] = 0;   // (first use behind the first request's barriers)
+  if (w4 == 0 && lane == 0) msync[0] = 0;   // (first PV wave; first use behind the first request's barriers)
   // "my partial rows of a split request are in memory" signal of this wave, owed to the request's merging piece: sent behind the
   // NEXT s_waitcnt vmcnt(0) the wave executes anyway (the next request's R0, or the end of the workgroup)
   int* pend_ctr = nullptr;
@@ -737,7 +749,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       const uint8_t* sn = src_of(t);
       uint8_t* dst = ring(t) + w4 * (kPiecesPerWave * 1024);
 #pragma unroll
-      for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s(sn, dn_off<FMT>(lc, k), dst + k * 1024);
+      for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s_nt<NT>(sn, dn_off<FMT>(lc, k), dst + k * 1024);
     };
     const float* lm = reinterpret_cast<const float*>(smem + kOffLm) + rt * 192;
 
@@ -773,7 +785,10 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       // joined inside a loop make hipcc copy the O registers at the join).
 #define FL_Y_PV_STEP(HAS_PREV, HAS_DMA)                                                                                \
   {                                                                                                                    \
-    if (i + 1 < n) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* page i landed, page i+1 may stay in flight */      \
+    if (i + 1 < n) { /* page i landed, page i+1 (this wave's kPiecesPerWave pieces) may stay in flight */               \
+      if constexpr (NRT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                        \
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                                          \
+    }                                                                                                                  \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
     FL_T(0); /* page-landed wait */                                                                                    \
@@ -783,13 +798,13 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     const uint8_t* sn = HAS_DMA ? src_of(i + 2) : nullptr;                                                             \
     uint8_t* dst = ring(i + 2) + w4 * (kPiecesPerWave * 1024);                                                         \
     if (HAS_PREV) {                                                                                                    \
-      pv_step<HAS_DMA, FMT>(o, m_o, lc, lane, ring(i - 1) + W * 256,                                                  \
+      pv_step<HAS_DMA, FMT, NRT, NT>(o, m_o, lc, lane, ring(i - 1) + W * 256,                                                  \
                        smem + kOffPbuf + ((i - 1) & 1) * kPbufPerParity + rt * (2 * 64 * 16),                          \
                        reinterpret_cast<const float*>(smem + kOffRef + ((i - 1) & 1) * kRefPerParity) + rt * 64, sn,   \
                        dst FL_T_ARGS);                                                                                 \
     } else {                                                                                                           \
       if (HAS_DMA) {                                                                                                   \
-        _Pragma("unroll") for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s(sn, dn_off<FMT>(lc, k), dst + k * 1024);      \
+        _Pragma("unroll") for (int k = 0; k < kPiecesPerWave; ++k) fl_dma16_s_nt<NT>(sn, dn_off<FMT>(lc, k), dst + k * 1024);      \
       }                                                                                                                \
     }                                                                                                                  \
     /* tail of the sequence: zero the rows of page i past the end (P' is exactly 0 there, but 0 * NaN from stale fp8   \
@@ -798,7 +813,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       const int nvalid = L - (tile_b + i) * kPage;                                                                     \
       uint8_t* wr = ring(i);                                                                                           \
       _Pragma("clang loop vectorize(disable) unroll(disable)")                                                         \
-      for (int T = nvalid + 2 * w4 + lh; T < kPage; T += 8)                                                            \
+      for (int T = nvalid + 2 * w4 + lh; T < kPage; T += 2 * kRoleWaves)                                               \
         *reinterpret_cast<uint4*>(wr + T * kDN + li * 16) = make_uint4(0, 0, 0, 0);                                    \
     }                                                                                                                  \
     FL_T(2); /* PV + refill issue */                                                                                   \
@@ -860,7 +875,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
     // RNE) and staged as [32 rows][256 bf16] (+16 B pad), then leave as 256-B row segments, 4 rows per store instruction.
     {
       uint8_t* stg = smem + kOffRing + w4 * (32 * kStgBytes);
-      const int row0 = rgrp * 64 + rt * 32;
+      const int row0 = rgrp * (32 * NRT) + rt * 32;
       int* ctr = g_merge_ctr + (long long)part * FL_MLA_META_W + 5 + (rgrp >> 1);   // (merging piece: split_idx == 0)
       // first look at the counter: issued here, used behind the staging (its round trip runs under the conversions)
       int arrived = merger ? __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
@@ -927,7 +942,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
       } else {
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const int sh = 16 * (rgrp & 1);
-        const int tgt = 4 * (nsplit - 1);
+        const int tgt = kRoleWaves * (nsplit - 1);   // one count per PV wave of every other piece
         FL_T(4);   // epilogue
         // BOUNDED poll: the counter must be exactly 0 at entry (K3 zeroes it, the merging workgroup puts it back) and launches that
         // share one metadata tensor must be ordered on one stream (include/fluent_mi355.h) — a stale or double count (an aborted launch, two
@@ -945,7 +960,7 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
         FL_T(7);   // merging piece: wait for the other pieces
         if (lane == 0) {   // the last of the four PV waves past the poll puts the counter back (the same metadata serves every layer's launch)
           const int old = __hip_atomic_fetch_add(msync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if ((old & 3) == 3) __hip_atomic_fetch_sub(ctr, tgt << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (old % kRoleWaves == kRoleWaves - 1) __hip_atomic_fetch_sub(ctr, tgt << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const uint16_t* parts = reinterpret_cast<const uint16_t*>(p.o_accum);
         auto ld16 = [&](const uint16_t* src) {
@@ -1082,7 +1097,8 @@ __global__ __launch_bounds__(512) void mla_decode_y_kernel(
 
 int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipStream_t stream) {
   Params p = p_in;
-  p.row_groups = (p.rows + 63) / 64;
+  const int nrt = p.rows > 32 ? 2 : 1;   // row tiles per workgroup: 64-row workgroups of 8 waves, or 32-row workgroups of 4 (TP8 shard: H = 16)
+  p.row_groups = (p.rows + 32 * nrt - 1) / (32 * nrt);
   p.partial_bf16 = 1;   // split partials travel as bf16 rows
   static const int merge_env = [] {   // FLUENT_MLA_MERGE_KERNEL=1: always the merge kernel; =0: always in-kernel (tests); unset: the rule below
     const char* e = getenv("FLUENT_MLA_MERGE_KERNEL");
@@ -1093,19 +1109,28 @@ int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipSt
   // (tools/bench_one_batch.py, 61-layer step, seq 4096, H = 128): bs = 64 (2 pieces) 4.38-4.41 ms in-kernel vs 4.46 with the merge
   // kernel; bs = 32 (4 pieces) 3.23 vs 2.99; bs = 16 3.00 vs 2.32; bs = 1 4.55 vs 1.79
   p.merge_in_kernel = (p.row_groups <= 6 && (merge_env == 0 || (merge_env < 0 && 2 * p.bs >= p.num_parts))) ? 1 : 0;
-  const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(512);
-  if (a->kv_format == FL_KV_FP8_576)
-    mla_decode_y_kernel<1><<<grid, block, 0, stream>>>(
-        p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, const_cast<int32_t*>(a->tile_scheduler_metadata), a->num_splits,
-        (const uint8_t*)a->k_nope, (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
-  else if (p.q_bf16 != nullptr)
-    mla_decode_y_kernel<0, true><<<grid, block, 0, stream>>>(
-        p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, const_cast<int32_t*>(a->tile_scheduler_metadata), a->num_splits,
-        (const uint8_t*)a->k_nope, (const uint16_t*)a->k_rope, a->k_scale, nullptr, nullptr, nullptr);
-  else
-  mla_decode_y_kernel<0><<<grid, block, 0, stream>>>(
-      p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, const_cast<int32_t*>(a->tile_scheduler_metadata), a->num_splits,
-      (const uint8_t*)a->k_nope, (const uint16_t*)a->k_rope, a->k_scale, (const uint8_t*)a->q_nope, (const uint16_t*)a->q_rope, a->q_scale);
+  const dim3 grid((unsigned)(p.num_parts * p.row_groups)), block(256 * nrt);
+#define FL_Y_LAUNCH1(FMT_, QBF_, NRT_, NT_, QN_, QR_, QS_)                                                              \
+  mla_decode_y_kernel<FMT_, QBF_, NRT_, NT_><<<grid, block, 0, stream>>>(                                               \
+      p, a->block_table, a->cache_seqlens, a->tile_scheduler_metadata, const_cast<int32_t*>(a->tile_scheduler_metadata), \
+      a->num_splits, (const uint8_t*)a->k_nope, (const uint16_t*)a->k_rope, a->k_scale, QN_, QR_, QS_)
+  // (one row group per request = one reader per page: non-temporal page stream)
+#define FL_Y_LAUNCH(FMT_, QBF_, NRT_, QN_, QR_, QS_)                                                                    \
+  do {                                                                                                                  \
+    if (NRT_ == 1 || p.row_groups == 1) FL_Y_LAUNCH1(FMT_, QBF_, NRT_, true, QN_, QR_, QS_);                            \
+    else FL_Y_LAUNCH1(FMT_, QBF_, NRT_, false, QN_, QR_, QS_);                                                          \
+  } while (0)
+  const uint8_t* qn = (const uint8_t*)a->q_nope;
+  const uint16_t* qr = (const uint16_t*)a->q_rope;
+  if (a->kv_format == FL_KV_FP8_576) {
+    if (nrt == 2) FL_Y_LAUNCH(1, false, 2, qn, qr, a->q_scale); else FL_Y_LAUNCH(1, false, 1, qn, qr, a->q_scale);
+  } else if (p.q_bf16 != nullptr) {
+    if (nrt == 2) FL_Y_LAUNCH(0, true, 2, nullptr, nullptr, nullptr); else FL_Y_LAUNCH(0, true, 1, nullptr, nullptr, nullptr);
+  } else {
+    if (nrt == 2) FL_Y_LAUNCH(0, false, 2, qn, qr, a->q_scale); else FL_Y_LAUNCH(0, false, 1, qn, qr, a->q_scale);
+  }
+#undef FL_Y_LAUNCH
+#undef FL_Y_LAUNCH1
   FL_CHECK_LAUNCH("mla_decode_y_kernel");
   // split requests are merged inside the kernel by their first piece (six 16-bit arrival counters per part: up to 6 row
   // groups); beyond that, or with FLUENT_MLA_MERGE_KERNEL=1, the separate merge kernel runs

@@ -49,7 +49,7 @@ class OneShotComm:
         self.rank, self.world, self.hidden = int(rank), int(world), int(hidden)
         self.max_tokens = min(int(max_tokens), MAX_ONESHOT_TOKENS)
         if timeout_s is None and os.environ.get("FLUENT_ONESHOT_TIMEOUT_S"):
-            timeout_s = float(os.environ["FLUENT_ONESHOT_TIMEOUT_S"])   # default (C side): 120 s
+            timeout_s = float(os.environ["FLUENT_ONESHOT_TIMEOUT_S"])   # default (C side): 10 s
         self._h = None
         if exchange is None:
             def exchange(obj):

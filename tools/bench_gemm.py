@@ -70,7 +70,7 @@ def run(T, iters):
         "down": {"ms": round(t2 * 1e3, 3), "TFLOPs": round(f2 / t2 / 1e12, 1), "mfma_frac": round(f2 / t2 / 1e12 / MFMA_PEAK_TF, 4), "GBs": round(b2 / t2 / 1e9, 1), "hbm_frac": round(b2 / t2 / 1e9 / HBM_PEAK, 4)},
         "moe_layer_ms(quant+gemm+silu+quant+gemm)": round(tl * 1e3, 3)}))
 
-for T, it in ((128, 20), (1024, 10), (2048, 8), (4096, 6), (6144, 5), (8192, 4), (16384, 3)):
+for T, it in ((128, 20), (256, 20), (512, 16), (1024, 10), (2048, 8), (4096, 6), (6144, 5), (8192, 4), (16384, 3)):
     if (len(sys.argv) > 1 and str(T) not in sys.argv[1:]) or (len(sys.argv) == 1 and T not in (128, 1024, 16384)):
         continue
     run(T, it)

@@ -1,7 +1,7 @@
 """GPU box: is the compute-regime grouped GEMM power-limited?  Runs the w13 GEMM of BASELINE config 3 (T = 16384) in a loop for a
 few seconds per variant while `rocm-smi` samples socket power and shader clock, for (a) the path's own random operands and
 (b) all-zero operands (no data toggling: if the chip is at its power cap, zeros clock higher and run faster at the same
-instruction stream).  usage: FLUENT_GEMM_BIG=1|2 python tools/gemm_power_probe.py"""
+instruction stream).  usage: [FLUENT_GEMM_BIG=0] python tools/gemm_power_probe.py   (0: the 128-row tiles; default: the 256 x 256 kernel)"""
 import json, os, subprocess, sys, threading, time, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sglang-fluentllm_amd"))
@@ -47,7 +47,7 @@ def run(tag, W, A):
     stop.set(); th.join()
     ms = e0.elapsed_time(e1) / n
     pw = [p for p, _ in samples if p]; sc = [s for _, s in samples if s]
-    print(json.dumps({"variant": tag, "big": os.environ.get("FLUENT_GEMM_BIG", "default"), "ms": round(ms, 3),
+    print(json.dumps({"variant": tag, "big": "128-row tiles" if os.environ.get("FLUENT_GEMM_BIG") == "0" else "256 x 256 tiles (default)", "ms": round(ms, 3),
                       "TFLOPs": round(2.0 * M * N * K / ms / 1e9, 1), "power_W_mean": round(sum(pw) / max(len(pw), 1), 1),
                       "power_W_max": max(pw) if pw else None, "sclk_MHz_mean": round(sum(sc) / max(len(sc), 1)) if sc else None,
                       "samples": len(samples)}), flush=True)

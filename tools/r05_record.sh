@@ -1,0 +1,16 @@
+# GPU box: the round's record — full GPU suite, PMC passes of the final K1 (cfg2 and the TP8 shard), kernel trace of the bench, the bench line
+set -x
+O=gpurun_out/r05_record; mkdir -p $O
+python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+bash tools/rocprof_pmc.sh $O/pmc_cfg2 > $O/pmc_cfg2.log 2>&1
+python tools/pmc_summary.py $O/pmc_cfg2 > $O/pmc_cfg2_summary.txt 2>&1
+PROF_ARGS="2 2 16 128 4096" bash tools/rocprof_pmc.sh $O/pmc_h16 > $O/pmc_h16.log 2>&1
+python tools/pmc_summary.py $O/pmc_h16 > $O/pmc_h16_summary.txt 2>&1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-gemm > $O/bench_profiled.json 2> $O/bench_profiled.err
+DB=$(find $O/kt -name "*.db" | head -1); [ -n "$DB" ] && python tools/rocpd_stats.py $DB > $O/kernel_trace_stats.txt 2>&1
+head -12 $O/kernel_trace_stats.txt
+python bench.py > $O/bench.json 2> $O/bench.err; tail -c 3000 $O/bench.json
+FLUENT_MI355_LIB=$PWD/sglang-fluentllm_amd/fluent_mi355/libfluent_exp_GEMMOLD.so python tools/bench_gemm.py > $O/bench_gemm_before_nt.txt 2>&1
+python tools/bench_gemm.py > $O/bench_gemm_nt.txt 2>&1
+head -3 $O/bench_gemm_before_nt.txt $O/bench_gemm_nt.txt

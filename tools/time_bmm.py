@@ -1,5 +1,5 @@
 """GPU box: the weight-absorption bmm's (B1 / B2, csrc/bmm_bf16.hip) at decode sizes, hipGraph of 8 calls.
-usage: [FLUENT_BMM_WLDS=0|1] python tools/time_bmm.py [T ...]"""
+usage: python tools/time_bmm.py [T ...]   (FLUENT_MI355_LIB selects another build of the library)"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sglang-fluentllm_amd"))
@@ -37,6 +37,6 @@ for T in (int(a) for a in (sys.argv[1:] or ["16", "128", "256"])):
     tq = timeit(lambda: bmm(q[..., :128].transpose(0, 1), wkc, out=Q[..., :512].transpose(0, 1)))
     tv = timeit(lambda: bmm(att.transpose(0, 1), wvc))
     tt = timeit(lambda: torch.bmm(att.transpose(0, 1), wvc))
-    print(json.dumps({"wlds": os.environ.get("FLUENT_BMM_WLDS", "default"), "T": T, "H": H, "q_absorb_us": round(tq, 1), "v_absorb_us": round(tv, 1),
+    print(json.dumps({"T": T, "H": H, "q_absorb_us": round(tq, 1), "v_absorb_us": round(tv, 1),
                       "torch_bmm_v_absorb_us": round(tt, 1),
                       "router_gemm_f32_us": round(tr, 1), "torch_linear_bf16_router_us": round(tl, 1)}))

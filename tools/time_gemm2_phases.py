@@ -3,7 +3,6 @@ build: tools/build_gemm_exp.sh G2T "-DFL_GEMM2_TIMING -DFL_GEMM_BIG_DEFAULT=2").
 import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["FLUENT_MI355_LIB"] = os.path.join(ROOT, "sglang-fluentllm_amd", "fluent_mi355", os.environ.get("GT_LIB", "libfluent_exp_G2T.so"))
-os.environ["FLUENT_GEMM_BIG"] = "2"
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sglang-fluentllm_amd"))
 import torch, numpy as np
 import deep_gemm

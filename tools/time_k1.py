@@ -43,5 +43,5 @@ for _ in range(reps): g.replay()
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / (reps * layers)
 alg = bench.algorithmic_bytes(bs, seq, H, 1)
-tag = "X" if os.environ.get("FLUENT_MLA_X") == "1" else "default"
+tag = "default"
 print(f"{os.environ.get('FLUENT_MLA_LIB_TAG', tag)} H={H} bs={bs} seq={seq}: {us:.1f} us/launch (graph replay)  {alg/us/1e3:.0f} GB/s ({alg/us/1e3/8000*100:.1f}% of 8 TB/s)")

@@ -1,5 +1,5 @@
 """GPU box: K2-fp8 (flash_mla_with_kvcache over one plain-fp8 [.,576] cache, device-scalar descales) at the cfg2 shape:
-us per launch in a hipGraph over `layers` caches.  FLUENT_MLA_Y=0 selects round 1's scheduling (128-row workgroups + merge)."""
+us per launch in a hipGraph over `layers` caches.  FLUENT_MI355_LIB selects another build of the library."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sglang-fluentllm_amd"))

@@ -23,7 +23,8 @@ if os.environ.get("SHARE_PAGES"):   # experiment: groups of k requests read the 
 meta, ns = fm.get_mla_metadata(wl["seqlens"], H, 1)
 qn, qs, qr = fm.quantize_ckv_per_token_head(wl["q"], 512)
 pages = wl["pages"]
-nblocks = meta.shape[0] * ((H + 63) // 64)
+NRT = 1 if H <= 32 else 2            # row tiles per workgroup: 4-wave workgroups for <= 32 query rows per request, 8-wave otherwise
+nblocks = meta.shape[0] * ((H + 32 * NRT - 1) // (32 * NRT))
 REC = 14
 dbg = torch.zeros(nblocks * 8 * REC * 2, dtype=torch.int32, device=dev)
 lib.fl_mla_debug_set_buffer_y.argtypes = [ctypes.c_void_p]
@@ -40,7 +41,7 @@ TICK = 10.0   # print unit: ticks x 10 (the counter runs at roughly the shader c
 QK = ["barrier wait", "deferred sums + next scale prep (after publish)", "loop control", "LDS drain", "B_n + normalisers + E0", "request prologue",
       "  K operand reads + MFMA issue", "  half-max exchange (permlane)", "  rope/scale load issue", "  MFMA drain + scaling + max", "  exp2 + e4m3 + publish", "  (mid barrier)"]
 PV = ["page-landed wait (vmcnt)", "barrier wait", "PV MFMAs + V^T reads + refill issue", "E0", "epilogue (store)", "request prologue", "  (to mid barrier)", "merge: wait for the other pieces", "merge: read + combine + store"] + ["-"] * 3
-for role, sl, names in (("QK waves", slice(0, 4), QK), ("PV waves", slice(4, 8), PV)):
+for role, sl, names in (("QK waves", slice(0, 2 * NRT), QK), ("PV waves", slice(2 * NRT, 4 * NRT), PV)):
     x = d[:, sl, :].reshape(-1, REC)
     x = x[x[:, 12] > 0]
     life = x[:, 12]

@@ -1,5 +1,5 @@
 """GPU box: the fused K5 + K4 launch (fl_mla_quant_q_store_k) at the bench shape: bs new K rows + bs*H query rows, hipGraph of 8 calls over
-distinct inputs.  usage: [FLUENT_QK_FORM=1|2|4|16|32] python tools/time_quant.py [bs] [H]"""
+distinct inputs.  usage: python tools/time_quant.py [bs] [H]   (FLUENT_MI355_LIB selects another build of the library)"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sglang-fluentllm_amd"))
@@ -33,4 +33,4 @@ for _ in range(50): gr.replay()
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / 400
 byt = bs * H * (576 * 2 + 512 + 128 + 4) + bs * (576 * 2 + 644)
-print(json.dumps({"form": os.environ.get("FLUENT_QK_FORM", "default"), "bs": bs, "H": H, "us": round(us, 2), "GBs": round(byt / us / 1e3, 1)}))
+print(json.dumps({"bs": bs, "H": H, "us": round(us, 2), "GBs": round(byt / us / 1e3, 1)}))
