@@ -44,6 +44,12 @@ __device__ __forceinline__ uint16_t fl_f32_to_bf16(float f) {
   const uint32_t n = (u >> 16) | 0x40u;
   return (uint16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? n : r);   // branch-free select
 }
+// max of three in one instruction (hipcc emits two v_max_f32 for nested fmaxf)
+__device__ __forceinline__ float fl_max3(const float a, const float b, const float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 // two f32 -> packed bf16 pair (lo = a), hardware RNE (v_cvt_pk_bf16_f32; same rounding as fl_f32_to_bf16 / torch)
 typedef __bf16 fl_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float fl_f32x2 __attribute__((ext_vector_type(2)));

@@ -86,11 +86,6 @@ __device__ __forceinline__ unsigned dn_off(const PvLane& lc, const int k) {
   return lc.dn_row + (unsigned)k * (FMT == 1 ? 1152u : 1024u) + (lc.dn_x ^ ((unsigned)(k & 7) << 5));
 }
 
-__device__ __forceinline__ float fl_max3(const float a, const float b, const float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
 // the eight K operand chunk addresses of a lane (ring slot base included): chunk pair of k-step s (and s + 4 at + 256) at
 // kaddr[2 (s&3)], kaddr[2 (s&3) + 1].  base is a multiple of 16 KiB and kb0 < 16 KiB: (base + kb0) ^ c == base + (kb0 ^ c).
 __device__ __forceinline__ void qk_addr(int (&kaddr)[8], const int kb0_in, const int base) {

@@ -1,5 +1,6 @@
 """GPU parity tests (run on the MI355X box: pytest -m gpu).  Everything goes through the drop-in modules
 (`flash_mla_fp8`) -> ctypes -> C-ABI -> HIP kernels and is compared with the oracle / golden vectors."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -317,9 +318,9 @@ def test_decode_rescale_branch_spike(fm):
 
 @pytest.mark.parametrize("H", [16, 64, 128])
 def test_decode_reference_jump_beyond_block_scale_range(fm, H):
-    """A key late in the sequence beats the first page's maximum by > 69 nats for one query row: the fixed-O-reference
-    mapping (s_q*H > 32) cannot express that jump as an E8M0 block scale and repeats the request with the reference preset
-    (the `redo` vote — with loader waves at H = 64); the 64-row mapping takes its O-rescale branch."""
+    """A key late in the sequence beats the first page's maximum by ~148 nats (213 log2 units) for one query row: beyond the 128 log2 units
+    of headroom the O reference starts with, so the kernel moves that row's reference up in place (O *= 2^-k in the step's out-of-line block;
+    rounds 2-4 repeated the request — the `redo` pass).  Every row count runs the same kernel template: 4 waves at H = 16, 8 at H = 64 / 128."""
     from oracle import mla_ref as R
 
     c = make_paged_case([1500, 200], H, seed=21)
@@ -840,3 +841,23 @@ def test_split_merge_inside_the_decode_kernel_on_every_split_case():
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1500:]
+
+
+@pytest.mark.parametrize("beside_gemm", ["0", "1"])
+def test_in_kernel_split_merge_is_deterministic_and_makes_progress_beside_a_gemm(beside_gemm):
+    """tools/determinism_ragged.py as a test: the ragged cfg2 workload (~122 requests split in two, merged inside the
+    decode kernel by their first piece, which polls the other pieces' arrival counter) launched 120 times on ONE metadata tensor — every
+    output bit-identical to the first, the counters back to zero.  BESIDE_GEMM=1: a compute-regime grouped GEMM (one 8-wave workgroup per
+    CU) owns the CUs on a second stream the whole time, so the decode workgroups are dispatched late and out of step and the merging piece
+    really waits for pieces that have not started: forward progress of the bounded poll under CU contention (run under a timeout)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "determinism_ragged.py"), "120"], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, BESIDE_GEMM=beside_gemm))
+    assert r.returncode == 0, r.stderr[-1500:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["beside_gemm"] == (beside_gemm == "1") and rec["iterations"] == 120 and rec["split_requests"] > 100
+    assert rec["mismatching_launches"] == 0 and rec["merge_counters_back_to_zero"], rec

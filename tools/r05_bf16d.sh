@@ -1,0 +1,3 @@
+#!/bin/bash
+cd /root/repo; mkdir -p gpurun_out
+{ timeout 300 python tools/time_phases_bf16.py 128 128 4096; SMALLSET=64 timeout 300 python tools/time_phases_bf16.py 128 128 4096; timeout 300 python tools/time_phases_bf16.py 16 128 4096; timeout 300 python tools/time_phases_bf16.py 64 128 4096; } 2>&1 | grep -v Warning | tee gpurun_out/bf16_phases.log
