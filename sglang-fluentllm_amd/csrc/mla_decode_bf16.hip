@@ -46,7 +46,10 @@ template <int NRT> struct Lay {
   static constexpr int kRows = 32 * NRT;
   static constexpr int kPieces = 18 / NRT;   // LDS-DMA pieces of 1 KiB per PV wave and tile (36 in all)
   static constexpr int kThreads = 256 * NRT;
-  static constexpr int kPBytes = kRows * 64;
+  // a row's 32 weights (64 B) sit in an 80-B line: at a 64-B pitch the 16 rows of a b128 read group share 4 bank sets (4-way) and the b32
+  // stores of a 32-lane group 4 banks (8-way) — 320 conflict cycles per tile step (SQ_LDS_BANK_CONFLICT with the K / V^T reads removed)
+  static constexpr int kPPitch = 80;
+  static constexpr int kPBytes = kRows * kPPitch;
   static constexpr int kOffF = kOffP + 2 * kPBytes;       // [parity 2][rows] f32 rescale factor of O before adding the tile
   static constexpr int kOffLm = kOffF + 2 * kRows * 4;    // [rows] l, [rows] m (epilogue)
   static constexpr int kLds = kOffLm + 2 * kRows * 4;
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(Lay<NRT>::kThreads, 2) void mla_decode_bf16_kernel(
         // P -> LDS in the PV MFMA's B-operand order: the row's 64-B line, token T at position q(T) = 16 (T >> 4) + 8 ((T >> 1) & 1) + (T & 1) +
         // 2 ((T >> 3) & 1) + 4 ((T >> 2) & 1) — the inverse of the PV waves' V^T read order (there: why).  This lane's tokens 16 tt + 4 g + r:
         // pairs r = (0, 1) at position 16 tt + 2 (g >> 1) + 4 (g & 1), r = (2, 3) eight further.
-        uint8_t* prow = smem + kOffP + (i & 1) * kPBytes + (wave * 16 + r16) * 64 + 4 * (g >> 1) + 8 * (g & 1);
+        uint8_t* prow = smem + kOffP + (i & 1) * kPBytes + (wave * 16 + r16) * L_::kPPitch + 4 * (g >> 1) + 8 * (g & 1);
         *reinterpret_cast<uint32_t*>(prow) = fl_pack_bf16(pv[0], pv[1]);
         *reinterpret_cast<uint32_t*>(prow + 16) = fl_pack_bf16(pv[2], pv[3]);
         *reinterpret_cast<uint32_t*>(prow + 32) = fl_pack_bf16(pv[4], pv[5]);
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(Lay<NRT>::kThreads, 2) void mla_decode_bf16_kernel(
       step_head(i);
       // ---- O^T += V^T(tile i - 1) . P^T(i - 1) ----
       const uint8_t* rd = slot(i - 1);
-      const uint8_t* pb = smem + kOffP + ((i - 1) & 1) * kPBytes + (rt * 32 + li) * 64 + lh * 16;
+      const uint8_t* pb = smem + kOffP + ((i - 1) & 1) * kPBytes + (rt * 32 + li) * L_::kPPitch + lh * 16;
       const uint4 p0 = *reinterpret_cast<const uint4*>(pb);        // k-step 0: positions 8 lh .. + 7 of the row's line (q(T) above)
       const uint4 p1 = *reinterpret_cast<const uint4*>(pb + 32);   // k-step 1
       const float f = fbuf[((i - 1) & 1) * kRows + rt * 32 + li];

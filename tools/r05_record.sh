@@ -11,6 +11,5 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py -
 DB=$(find $O/kt -name "*.db" | head -1); [ -n "$DB" ] && python tools/rocpd_stats.py $DB > $O/kernel_trace_stats.txt 2>&1
 head -12 $O/kernel_trace_stats.txt
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 3000 $O/bench.json
-FLUENT_MI355_LIB=$PWD/sglang-fluentllm_amd/fluent_mi355/libfluent_exp_GEMMOLD.so python tools/bench_gemm.py > $O/bench_gemm_before_nt.txt 2>&1
-python tools/bench_gemm.py > $O/bench_gemm_nt.txt 2>&1
-head -3 $O/bench_gemm_before_nt.txt $O/bench_gemm_nt.txt
+CACHES=2 LAUNCHES=2 KREGEX=mla_decode_bf16 PROF_SCRIPT=tools/time_k2_bf16.py PROF_ARGS="128 128 4096" bash tools/rocprof_pmc.sh $O/pmc_bf16 > $O/pmc_bf16.log 2>&1
+KREGEX=mla_decode_bf16 python tools/pmc_summary.py $O/pmc_bf16 > $O/pmc_bf16_summary.txt 2>&1
