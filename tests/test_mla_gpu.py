@@ -699,6 +699,33 @@ def test_flash_mla_with_kvcache_bf16(fm, lens, H, s_q):
     assert float((lse[m].double() - rlse[m]).abs().max()) < 2e-3, lens
 
 
+@pytest.mark.parametrize("H", [16, 64, 128])
+def test_bf16_reference_jump_moves_the_row_reference_in_place(fm, H):
+    """mla_decode_bf16.hip keeps a row's reference FIXED 24 log2 units above its first tile's maximum and moves it only when a later tile beats
+    it by more than 2^64 (O *= 2^-k out of line, l alike).  A key planted late in the sequence that matches query row 3 with a logit ~190 log2
+    units above the rest forces that move; the other rows of the request and the second request must not notice.  4 waves at H = 16, 8 above."""
+    import flash_mla_swap
+    lens = [1500, 200]
+    q, kc, bt, seq, pages = make_bf16_576_case(lens, H, 1, seed=31 + H)
+    t = 1400
+    slot = int(bt[0, t // 64]) * 64 + t % 64
+    kc[slot, 0, :512] = (q[0, 0, 3, :512].float() * 4.0).to(torch.bfloat16)
+    kc[slot, 0, 512:] = 0
+    meta, ns = flash_mla_swap.get_mla_metadata(seq.to(dev()), H, 1)
+    o, lse = flash_mla_swap.flash_mla_with_kvcache(q.to(dev()), kc.to(dev()).view(pages, 64, 1, 576), bt.to(dev()), seq.to(dev()), 512, meta, ns,
+                                                   SCALE, True)
+    torch.cuda.synchronize()
+    ref, rlse = mla_ref.mla_decode_with_kvcache(q, torch.nan_to_num(kc).view(pages, 64, 1, 576), bt, seq, 512, SCALE, True)
+    o, lse = o.cpu(), lse.cpu()
+    jump = float(rlse[0, 3, 0] - rlse[0, 2, 0]) * 1.4427
+    assert jump > 100, jump                                       # (the planted logit really is beyond the 64 + 24 log2 units of slack)
+    assert torch.isfinite(o.float()).all()
+    assert rel_mae(o, ref) < 6e-3
+    assert float((lse.double() - rlse).abs().max()) < 2e-3 * max(1.0, float(rlse.abs().max()) / 50)
+    # the peaked row returns (almost exactly) the planted token's latent
+    assert float((o[0, 0, 3].double() - ref[0, 0, 3]).abs().max()) < 2e-2 * float(ref[0, 0, 3].abs().max())
+
+
 def test_bf16_decode_vs_reference_backend_golden(fm):
     """The golden vectors are outputs of the REAL reference's TorchNativeAttnBackend over a bf16 KV buffer: the bf16
     kernel is compared with them directly (no quantisation in between)."""
