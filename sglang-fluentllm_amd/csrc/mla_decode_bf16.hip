@@ -12,20 +12,22 @@
 //   * QK waves a in [0, 2 NRT): query rows [16a, 16a + 16) x ALL 32 tokens of tile i on v_mfma_f32_16x16x32_bf16 ("SwapAB":
 //     S^T[16 tok x 16 rows] = K . Q^T, 2 token tiles x 18 k-steps = 36 MFMAs in two independent chains; the wave's Q fragment is 72
 //     VGPRs; the K fragments run 5 k-steps ahead of their MFMAs).  A lane holds 8 scores of ONE query row (lane & 15): tokens
-//     16 tt + 4 (lane >> 4) + r; the row maximum is a 2-step xor-shuffle over the four lane groups.  The ROWS are split over the
+//     16 tt + 4 (lane >> 4) + r; the row maximum crosses the four lane groups by v_permlane16_swap / v_permlane32_swap.  The ROWS are split over the
 //     waves, not the k steps: no partial sums travel and the softmax halves run side by side.  The row's reference is FIXED 24 log2
 //     units above its first valid tile's maximum (mla_decode_fp8_y.hip's O reference: weights above 1 are fine in bf16 / fp32) and
 //     moves only on a jump of more than 2^64; P = 2^(y - m) as bf16 -> LDS in the PV MFMA's B-operand order, the row's (almost
 //     always 1) rescale factor beside it.
 //   * PV waves (row tile rt, d half) one step later: O^T[256 dims x 32 rows] += V^T . P^T on v_mfma_f32_32x32x16_bf16 (8 dim tiles x
-//     2 k-steps), V^T by ds_read_b64_tr_b16 (3 MFMAs ahead) from the same LDS bytes the QK waves read as K.
+//     2 k-steps), V^T by ds_read_b64_tr_b16 (3 MFMAs ahead) from the same LDS bytes the QK waves read as K; the four tokens of a
+//     transpose-read group are (T, T+1, T+8, T+9): conflict-free (consecutive tokens: 38 % of the LDS cycles were conflicts).
 //   * 4-slot ring of 36 KiB tiles (tile i-1 read as V^T, tile i as K, tiles i+1, i+2 landing: two steps of flight), LDS-DMA
-//     (global_load_lds, 1 KiB per wave instruction): 12 / NRT pieces per PV wave behind its MFMAs (EXEC-masked past the last tile: no
-//     branch in the MFMA sequence), 6 / NRT per QK wave behind its chain; counted vmcnt, ONE s_barrier per tile step.  16-B chunks
+//     (global_load_lds, 1 KiB per wave instruction): the PV waves issue all 36 pieces of tile i+2 at the head of step i, in front of
+//     their MFMAs (18 / NRT each; a piece blocks its wave's issue for 50-100 cycles wherever it sits: between MFMAs it stretched the
+//     MFMA phase 2.5 x), the block-table entry read one step ahead; counted vmcnt, ONE s_barrier per tile step.  16-B chunks
 //     XOR-swizzled on the source address (chunk c of token T at (c & ~7) | ((c & 7) ^ ((T >> 1) & 7))): the K reads of a 16-lane
 //     group hit 16 distinct slots.  One row group per request: the pages stream non-temporal (nobody re-reads them from L2).
-// Bounds: LDS bandwidth at 64 rows per workgroup (244 KiB of LDS traffic per tile step), the two-tile flight
-// depth of the ring against HBM latency at 16 .. 32 rows.
+// Where it stands (profiles/r05_k2_bf16_rewrite.txt): H <= 32 streams 5.7-6.4 TB/s (the chip's LDS-DMA stream rate is 6.2-6.3); H = 128 is
+// at the bf16 ridge (242 FLOP/B) with 45 % matrix-pipe duty — flight depth, priorities and prefetch distances measured flat.
 #include "mla_decode_shared.h"
 
 using namespace fl_mla;
@@ -39,8 +41,7 @@ constexpr int kTile = 32;                       // tokens per tile
 constexpr int kRowB = (kDN + kDR) * 2;          // 1152 B per token
 constexpr int kTileBytes = kTile * kRowB;       // 36 KiB
 constexpr int kSlots = 4;
-// NRT = row tiles of 32 query rows per workgroup (1: 4 waves, 2: 8 waves sharing one tile ring).  LDS-DMA pieces of 1 KiB per wave and
-// tile: 2 NRT QK waves x 6 / NRT + 2 NRT PV waves x 12 / NRT = 36
+// NRT = row tiles of 32 query rows per workgroup (1: 4 waves, 2: 8 waves sharing one tile ring)
 constexpr int kOffP = kSlots * kTileBytes;      // [parity 2][32 NRT rows][32 tokens] bf16 in PV order
 template <int NRT> struct Lay {
   static constexpr int kRows = 32 * NRT;
