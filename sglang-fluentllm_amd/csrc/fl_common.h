@@ -102,9 +102,22 @@ __device__ __forceinline__ uint2 fl_div8_to_fp8(const float (&x)[8], const float
                     fl_cvt_pk_fp8(q[4], q[5]) | (fl_cvt_pk_fp8(q[6], q[7]) << 16));
 }
 
+// max over the 64 lanes, every lane gets it.  In registers: v_permlane32_swap / v_permlane16_swap across the four rows of 16, DPP row rotations and
+// quad permutations inside a row (max is order-free: the same bits as any other reduction order; __shfl_xor is six dependent ds_bpermute
+// round trips through the LDS crossbar — the quantise kernels' whole latency chain at decode sizes)
 __device__ __forceinline__ float fl_wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  {
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+  }
+  {
+    const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+  }
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));   // row_ror:8
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false)));   // row_ror:4
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false)));    // quad_perm:[2,3,0,1]
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false)));    // quad_perm:[1,0,3,2]
   return v;
 }
 
