@@ -363,9 +363,16 @@ int fl_rope(const FlRopeArgs* args, fl_stream_t stream);
  * with the semantics of `buf[tgt] = buf[src]` (:756-763): all sources are read before any target is written (overlapping
  * sets are safe).  data_ptrs / row_bytes: DEVICE tables [num_buffers] (base address, bytes per row; rows multiples of 4 B)
  * like the reference's data_ptrs / data_strides (:330-343); max_row_bytes = host-known maximum of row_bytes; tgt/src int64
- * DEVICE [num_locs], num_locs <= 8192; num_slots > 0: rows outside [0, num_slots) are skipped.  Bit-exact byte work. ---- */
+ * DEVICE [num_locs], num_locs <= 8192 (more: fl_kv_move_staged); num_slots > 0: rows outside [0, num_slots) are skipped.  Bit-exact byte work. ---- */
 int fl_kv_move(const uint64_t* data_ptrs, const int64_t* row_bytes, int num_buffers, int64_t max_row_bytes,
                const int64_t* tgt_loc, const int64_t* src_loc, int64_t num_locs, int64_t num_slots, fl_stream_t stream);
+/* The same move for MORE rows than fl_kv_move holds in registers (num_locs up to 4,194,240): two launches through a caller-owned staging
+ * area of num_locs x sum_row_bytes bytes (sum over the table's buffers) — every source row is copied out, then every target written: the
+ * same "all reads before any write" semantics.  row_prefix: DEVICE [num_buffers], exclusive prefix sums of row_bytes (buffer b's staging
+ * area starts at row_prefix[b] x num_locs).  A pair with either index outside [0, num_slots) is skipped. */
+int fl_kv_move_staged(const uint64_t* data_ptrs, const int64_t* row_bytes, const int64_t* row_prefix, int num_buffers,
+                      const int64_t* tgt_loc, const int64_t* src_loc, int64_t num_locs, int64_t num_slots, void* workspace,
+                      int64_t workspace_bytes, int64_t sum_row_bytes, fl_stream_t stream);
 
 /* ---- C8/C9: ep_scatter / ep_gather of the DeepExecutor (srt/layers/moe/executors/deep_ep_executor.py:271-332,
  * 396-430; Triton kernels :173-268, :335-393): between the DeepEP dispatch and the contiguous grouped GEMM, and back.

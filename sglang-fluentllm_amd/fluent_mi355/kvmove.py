@@ -13,6 +13,9 @@ from ._lib import check, lib, stream_ptr
 _i64, _vp, _i = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
 lib.fl_kv_move.argtypes = [_vp, _vp, _i, _i64, _vp, _vp, _i64, _i64, _vp]
 lib.fl_kv_move.restype = _i
+lib.fl_kv_move_staged.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp]
+lib.fl_kv_move_staged.restype = _i
+_MAX_ROWS_IN_REGISTERS = 8192   # csrc/kv_move.hip: kCap
 
 
 class KVMoveTable:
@@ -36,6 +39,12 @@ class KVMoveTable:
         self.max_row_bytes = max(row_bytes)
         self.data_ptrs = torch.tensor([b.data_ptr() for b in buffers], dtype=torch.int64).to(dev)   # (addresses < 2^63)
         self.row_bytes = torch.tensor(row_bytes, dtype=torch.int64).to(dev)
+        self.sum_row_bytes = sum(row_bytes)
+        prefix = [0]
+        for rb in row_bytes[:-1]:
+            prefix.append(prefix[-1] + rb)
+        self.row_prefix = torch.tensor(prefix, dtype=torch.int64).to(dev)   # staging layout of the > 8192-row path
+        self._staging = None
 
     def move(self, tgt_loc, src_loc):
         """rows tgt_loc[i] <- src_loc[i] in every buffer; sets may overlap (all reads precede all writes)"""
@@ -46,8 +55,19 @@ class KVMoveTable:
         dev = self.data_ptrs.device
         t = tgt_loc.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
         s = src_loc.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
-        check(lib.fl_kv_move(self.data_ptrs.data_ptr(), self.row_bytes.data_ptr(), len(self.buffers), self.max_row_bytes,
-                             t.data_ptr(), s.data_ptr(), t.numel(), self.num_slots, stream_ptr(dev)), "fl_kv_move")
+        n = t.numel()
+        if n <= _MAX_ROWS_IN_REGISTERS:
+            check(lib.fl_kv_move(self.data_ptrs.data_ptr(), self.row_bytes.data_ptr(), len(self.buffers), self.max_row_bytes,
+                                 t.data_ptr(), s.data_ptr(), n, self.num_slots, stream_ptr(dev)), "fl_kv_move")
+            return
+        # more rows than one workgroup holds between its reads and its writes: gather every source row into a staging area, then scatter
+        # (two launches, same semantics).  The area is kept and only grows; launches sharing it are ordered on the caller's stream.
+        need = n * self.sum_row_bytes
+        if self._staging is None or self._staging.numel() < need:
+            self._staging = torch.empty(need, dtype=torch.uint8, device=dev)
+        check(lib.fl_kv_move_staged(self.data_ptrs.data_ptr(), self.row_bytes.data_ptr(), self.row_prefix.data_ptr(), len(self.buffers),
+                                    t.data_ptr(), s.data_ptr(), n, self.num_slots, self._staging.data_ptr(), self._staging.numel(),
+                                    self.sum_row_bytes, stream_ptr(dev)), "fl_kv_move_staged")
 
 
 def move_kv_cache(buffers, tgt_loc, src_loc):

@@ -23,7 +23,7 @@ def test_kv_move_bit_exact_vs_reference_golden():
         assert torch.equal(got.cpu().view(torch.uint8), want.view(torch.uint8))
 
 
-@pytest.mark.parametrize("n,layers,shift", [(1, 3, 1), (256, 61, 3), (8192, 2, 64), (1000, 4, 0)])
+@pytest.mark.parametrize("n,layers,shift", [(1, 3, 1), (256, 61, 3), (8192, 2, 64), (1000, 4, 0), (8193, 2, 5), (20000, 3, 77)])
 def test_kv_move_compaction_vs_oracle(n, layers, shift):
     """A compaction like the speculative-decoding accept step: rows slide down by `shift` slots (sources and targets
     overlap; shift 0 = self-copy), per_token_head MLA buffers (512 B, 4 B, 128 B rows) and a bf16 [S, 576] cache, int32 locs."""
@@ -58,7 +58,18 @@ def test_kv_move_out_of_range_rows_are_skipped_and_limits():
     want[3] = before[4]
     assert torch.equal(buf, want)
     move_kv_cache([buf], torch.empty(0, dtype=torch.int64, device=DEV), torch.empty(0, dtype=torch.int64, device=DEV))
-    with pytest.raises(RuntimeError):
-        KVMoveTable([buf]).move(torch.zeros(8193, dtype=torch.int64, device=DEV), torch.zeros(8193, dtype=torch.int64, device=DEV))
+    # more than 8192 rows per call go through the staged path (gather, then scatter): same skip rule, same semantics
+    big = torch.arange(9000 * 16, dtype=torch.float32).view(9000, 16).to(DEV)
+    before = big.clone()
+    tgt = torch.arange(8500, device=DEV)
+    src = torch.arange(8500, device=DEV) + 100
+    tgt[17], src[18] = -1, 9000                       # two skipped pairs
+    KVMoveTable([big]).move(tgt, src)
+    torch.cuda.synchronize()
+    want = before.clone()
+    keep = torch.ones(8500, dtype=torch.bool, device=DEV)
+    keep[17] = keep[18] = False
+    want[tgt[keep]] = before[src[keep]]
+    assert torch.equal(big, want)
     with pytest.raises(RuntimeError):
         KVMoveTable([buf, torch.zeros(41, 16, device=DEV)])
