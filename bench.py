@@ -31,6 +31,111 @@ K4_IN_K1 = os.environ.get("FLUENT_BENCH_K4_IN_K1", "0") == "1"   # experiment sw
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling ~6290 GB/s
 
 
+class GpuSampler:
+    """~10 Hz sampler of shader clock and socket power around a measured loop (VERDICT r5 item 3: the power-cap argument belongs in the
+    driver's record).  Sources, first that answers: the amdgpu hwmon files of the device (no subprocess: freq1_input Hz, power1_average /
+    power1_input uW, power1_cap uW), then `rocm-smi --showpower --showclocks`.  Every field is None when nothing answers — the headline
+    never depends on it."""
+
+    def __init__(self, index=0, period=0.1):
+        import threading
+        self.index, self.period = index, period
+        self.stop_ev, self.samples, self.thread = threading.Event(), [], None
+        self.hw = self._find_hwmon(index)
+        self.cap = None
+
+    @staticmethod
+    def _find_hwmon(index):
+        import glob
+        cands = []
+        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+            if "-" in os.path.basename(card):
+                continue
+            for hm in sorted(glob.glob(os.path.join(card, "device/hwmon/hwmon*"))):
+                if os.path.exists(os.path.join(hm, "freq1_input")) and (os.path.exists(os.path.join(hm, "power1_average"))
+                                                                          or os.path.exists(os.path.join(hm, "power1_input"))):
+                    cands.append(hm)
+        if not cands:
+            return None
+        return cands[index] if index < len(cands) else cands[0]
+
+    @staticmethod
+    def _rd(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def _one(self):
+        if self.hw is not None:
+            f = self._rd(os.path.join(self.hw, "freq1_input"))
+            pw = self._rd(os.path.join(self.hw, "power1_average"))
+            if pw is None:
+                pw = self._rd(os.path.join(self.hw, "power1_input"))
+            if self.cap is None:
+                c = self._rd(os.path.join(self.hw, "power1_cap"))
+                self.cap = c / 1e6 if c else None
+            if f is not None or pw is not None:
+                return (f / 1e6 if f else None, pw / 1e6 if pw else None)
+        import re
+        import subprocess
+        try:
+            r = subprocess.run(["rocm-smi", "-d", str(self.index), "--showpower", "--showclocks", "--showmaxpower"], capture_output=True,
+                               text=True, timeout=5).stdout
+            pw = re.findall(r"(?:Average|Current)[^:]*Power[^:]*:\s*([0-9.]+)", r)
+            sc = re.findall(r"sclk clock level[^(]*\((\d+)Mhz\)", r)
+            mx = re.findall(r"Max Graphics Package Power[^:]*:\s*([0-9.]+)", r)
+            if mx and self.cap is None:
+                self.cap = float(mx[0])
+            return (float(sc[0]) if sc else None, float(pw[0]) if pw else None)
+        except Exception:
+            return (None, None)
+
+    def _loop(self):
+        while not self.stop_ev.is_set():
+            self.samples.append(self._one())
+            self.stop_ev.wait(self.period)
+
+    def __enter__(self):
+        import threading
+        self.thread = threading.Thread(target=self._loop, daemon=True)
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop_ev.set()
+        self.thread.join(timeout=10)
+        return False
+
+    def summary(self):
+        sc = [s for s, _ in self.samples if s]
+        pw = [p for _, p in self.samples if p]
+        return {"sclk_mhz_mean": round(sum(sc) / len(sc)) if sc else None, "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None,
+                "power_w_max": round(max(pw), 1) if pw else None, "power_cap_w": round(self.cap, 1) if self.cap else None,
+                "samples": len(self.samples), "source": "hwmon" if self.hw is not None else "rocm-smi"}
+
+
+def sampled_loop(fn, seconds=2.5, chunk=4, index=0):
+    """Runs fn() back to back for ~`seconds` under the sampler: (seconds per call, sampler summary).  The clock / power fields describe THIS
+    loop (same launches as the timed measurement, just long enough for a 10 Hz sampler to see them)."""
+    fn()
+    torch.cuda.synchronize()
+    n = 0
+    with GpuSampler(index) as sm:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.time()
+        e0.record()
+        while time.time() - t0 < seconds:
+            for _ in range(chunk):
+                fn()
+            n += chunk
+            torch.cuda.synchronize()
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / n, sm.summary()
+
+
 def algorithmic_bytes(bs, seq, h, s_q):
     """SURVEY §8(d): per (request, layer): seq*644 KV + s_q*H*644 Q (after K4) + s_q*H*1024 out + 4*ceil(seq/64)."""
     return bs * (seq * 644 + s_q * h * 644 + s_q * h * 1024 + 4 * ((seq + 63) // 64))
@@ -331,7 +436,7 @@ def gemm_roofline(dev):
     res = {"workload": "w13 grouped GEMM, 256 experts top-8 uniform routing, hidden 7168, 2 x inter 4096, fp8 e4m3 1x128 / 128x128 block scales",
            "operands": "N(0,1) through the path's quantisers (weights 128x128-block amax/448, activations 1x128)"}
 
-    def timed(T, iters, xq, xs, ex, M):
+    def timed(T, iters, xq, xs, ex, M, sample=None):
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
 
         def run():
@@ -345,6 +450,13 @@ def gemm_roofline(dev):
             run()
         e1.record()
         torch.cuda.synchronize()
+        if sample is not None:   # clock / power of the same launches over ~2 s
+            try:
+                s_, smp = sampled_loop(run, 2.0, 8)
+                smp["ms_sampled_loop"] = round(s_ * 1e3, 3)
+                sample.update(smp)
+            except Exception as ex_:
+                sample["error"] = f"{type(ex_).__name__}: {ex_}"[:200]
         return e0.elapsed_time(e1) * 1e-3 / iters
 
     for T, iters in ((128, 20), (16384, 3)):
@@ -360,13 +472,17 @@ def gemm_roofline(dev):
             q_, s_ = per_token_group_quant_fp8(torch.randn(min(16384, M - i), HID, device=dev, generator=g).to(torch.bfloat16))
             xq[i:i + q_.shape[0]].copy_(q_)
             xs[i:i + q_.shape[0]].copy_(s_)
-        t = timed(T, iters, xq, xs, ex, M)
+        smp = {} if T == 16384 else None
+        t = timed(T, iters, xq, xs, ex, M, smp)
         flops = 2.0 * M * N * HID
         hit = int((counts > 0).sum())
         byts = hit * (N * HID) + M * (HID + HID // 128 * 4) + M * N * 2
         res[f"T{T}"] = {"ms": round(t * 1e3, 3), "TFLOPs": round(flops / t / 1e12, 1),
                         "mfma_frac": round(flops / t / 1e12 / 5000.0, 4), "GBs": round(byts / t / 1e9, 1),
                         "hbm_frac": round(byts / t / 1e9 / HBM_PEAK_GBS, 4), "rows_per_expert": round(M / E, 1)}
+        if smp is not None:
+            res[f"T{T}"].update({"sclk_mhz_mean": smp.get("sclk_mhz_mean"), "power_w_mean": smp.get("power_w_mean"),
+                                 "power_cap_w": smp.get("power_cap_w"), "sampler": smp})
         if T == 16384:   # the same launch on uniformly random bytes (maximal operand toggling; round 1's operands)
             flat = w.view(-1).view(torch.uint8)
             step = 1 << 28
@@ -779,8 +895,32 @@ def main():
                 traffic = round(json.load(f)["hbm_bytes_per_launch"])
         except Exception:
             traffic_src = None
-        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        # at H = 128 the kernel is near the fp8 ridge — the MFMA fraction beside the HBM fraction (2176 flop per
+        # query row and token: QK 2 x 576, PV 2 x 512), and what the chip's clock / power did during the same launches
+        flops = 2176.0 * S_Q * H * SEQ * BS
+        mfma_frac = flops / per_launch_s / 5e15
+        smp, smp_s = None, None
+        try:
+            def replay_once():
+                if k1_graph is not None:
+                    k1_graph.replay()
+                else:
+                    for l_ in range(layers):
+                        k1(l_)
+            smp_s, smp = sampled_loop(replay_once, 2.5, 4, local_rank)
+            smp["us_per_launch_sampled_loop"] = round(smp_s / layers * 1e6, 2)
+        except Exception as ex_:
+            smp = {"error": f"{type(ex_).__name__}: {ex_}"[:200]}
+        capped = bool(smp and smp.get("power_w_mean") and smp.get("power_cap_w") and smp["power_w_mean"] >= 0.93 * smp["power_cap_w"])
+        # what binds: bytes (>= 0.6 of the HBM sheet rate is past the measured copy ceiling's 3/4) or the instruction stream under the
+        # socket power limit (matrix-pipe duty + clock: DESIGN.md section 3)
+        binding = "hbm" if achieved / HBM_PEAK_GBS >= 0.6 else "issue/power"
+        roof = {"bound": "hbm", "binding": binding, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "mfma_frac": round(mfma_frac, 4), "mfma_tflops": round(flops / per_launch_s / 1e12, 1),
+                "sclk_mhz_mean": smp.get("sclk_mhz_mean") if smp else None, "power_w_mean": smp.get("power_w_mean") if smp else None,
+                "power_cap_w": smp.get("power_cap_w") if smp else None, "power_capped": capped if smp and smp.get("power_w_mean") else None,
+                "sampler": smp,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "mla_decode_y_kernel (no merge kernel: split requests are merged inside the decode kernel; none is split at this shape)",
                 "us_per_launch": round(per_launch_s * 1e6, 2),
                 "algorithmic_bytes_per_launch": alg}

@@ -28,6 +28,14 @@ def test_bench_prints_one_json_line_with_the_contract_keys_and_the_config4_child
     roof = d["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / roof["us_per_launch"] / 1e3) / roof["achieved"] < 1e-2
+    # the compute-side fraction and the chip's clock / power during the same launches ride in the record
+    for k in ("mfma_frac", "binding", "sclk_mhz_mean", "power_w_mean", "power_cap_w"):
+        assert k in roof, k
+    assert roof["binding"] in ("hbm", "issue/power")
+    flops = 2176.0 * 128 * 4096 * 128
+    assert abs(roof["mfma_frac"] - flops / (roof["us_per_launch"] * 1e-6) / 5e15) < 2e-3
+    assert roof["sclk_mhz_mean"] is None or 300 <= roof["sclk_mhz_mean"] <= 3000
+    assert roof["power_w_mean"] is None or 50 <= roof["power_w_mean"] <= 2500
     c4 = d["cfg4"]
     assert c4 is not None and "error" not in c4, c4
     assert c4["value"] > 0 and c4["scaling"] == "strong" and c4["config"]["data_connected"] is True and "attempt" in c4
