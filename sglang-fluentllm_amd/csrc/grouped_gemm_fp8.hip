@@ -354,10 +354,11 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
   if (a->mode == kContiguous) mt = 4;   // groups are 128-row aligned by contract (deep_ep_executor.py:282,290)
   // many rows per group (prefill regime): 256 x 256 tiles, one 8-wave workgroup per CU (grouped_gemm_fp8_big2.hip).
   // FLUENT_GEMM_BIG=0 keeps the 128-row tiles for every shape (A/B runs); unset or empty: on.
-  static const bool big_on = [] {
+  static const int big_sel = [] {   // unset / empty: the round-6 192 x 256 one-wave-per-SIMD kernel where its shape rules allow, else big2
     const char* e = getenv("FLUENT_GEMM_BIG");
-    return !(e != nullptr && e[0] == '0');
+    return (e != nullptr && e[0] >= '0' && e[0] <= '9') ? e[0] - '0' : 3;
   }();
+  const bool big_on = big_sel != 0;
   // (contiguous groups are only 128-row aligned; the big tile addresses a weight panel with 32-bit offsets)
   // (measured, E = 256 top-8: 128 rows per expert: w13 872 vs 871, w2 816 vs 873 TFLOP/s with the 256 x 256 kernel; 64 rows per expert:
   //  559 vs 459 — the 128-row kernel stays below 128)
@@ -378,8 +379,11 @@ extern "C" int fl_grouped_gemm_fp8(const FlGemmArgs* a, fl_stream_t stream) {
   // (under a deep_gemm.set_num_sms cap the 128-row kernel's persistent tile walk is used: the 256 x 256 kernel is one
   //  workgroup per tile by construction)
   if (!few_tiles && big_on && avg >= big_min && a->K >= 2 * BK && a->mode != kContiguous &&
-      (long long)a->N * a->K < (1ll << 32) && g_num_cus_limit.load() == 0)
+      (long long)a->N * a->K < (1ll << 32) && g_num_cus_limit.load() == 0) {
+    if (big_sel >= 3 && a->N % 256 == 0 && a->K <= 64 * BK)
+      return fl_gemm_launch_big3(p, a->A, a->As, a->W, a->Ws, a->group_meta, (hipStream_t)stream);
     return fl_gemm_launch_big2(p, a->A, a->As, a->W, a->Ws, a->group_meta, (hipStream_t)stream);
+  }
   const int bm = 32 * mt;
   long long m_tiles;
   if (a->mode == kOffset) m_tiles = (a->M + bm - 1) / bm + a->num_groups;

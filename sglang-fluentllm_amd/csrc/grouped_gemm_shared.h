@@ -112,3 +112,6 @@ __device__ __forceinline__ bool locate_tile(const GemmParams& p, const int32_t* 
 // 256 x 256 tile kernel: many rows per group (grouped_gemm_fp8_big2.hip, round 3)
 int fl_gemm_launch_big2(const fl_gemm::GemmParams& p, const void* A, const float* As, const void* W, const float* Ws,
                         const int32_t* group_meta, hipStream_t stream);
+// 192 x 256 tile kernel, one wave per SIMD (grouped_gemm_fp8_big3.hip, round 6); needs N % 256 == 0 and K <= 8192
+int fl_gemm_launch_big3(const fl_gemm::GemmParams& p, const void* A, const float* As, const void* W, const float* Ws,
+                        const int32_t* group_meta, hipStream_t stream);
