@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("counts,N,K", [([192, 193, 1, 0, 383, 385, 200], 256, 256),
                                         ([512, 130, 700], 512, 384),
+                                        ([193, 225, 257, 289, 321, 353, 32, 64, 96, 128, 160], 256, 512),   # last tiles with 1..6 blocks of 32 rows: skipped MFMA groups
                                         ([191, 577, 0, 256], 768, 640),
                                         ([300] * 40, 1024, 256),            # 80 m tiles x 4 n tiles = 320 tiles > 256 CUs: carried tiles
                                         ([530, 490, 512, 600], 4096, 7168),   # BASELINE config 3 w13 shape, rows around 512

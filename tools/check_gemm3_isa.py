@@ -1,5 +1,5 @@
 """Build-time check of grouped_gemm_fp8_big3.hip's machine code (no GPU needed): (1) no compiler-generated instruction touches the fixed
-fragment registers a144..a255; (2) no asm VMEM statement reads an SGPR that a VALU instruction (v_readlane / v_readfirstlane / v_cmp ..)
+fragment registers a140..a255; (2) no asm VMEM statement reads an SGPR that a VALU instruction (v_readlane / v_readfirstlane / v_cmp ..)
 wrote fewer than 5 wait states earlier (hipcc's hazard recogniser does not look into asm statements).
 usage: python tools/check_gemm3_isa.py [file.s]   (default: compiles the kernel to /tmp/big3_check.s; G3FLAGS adds compiler flags)"""
 import os, re, subprocess, sys
@@ -40,7 +40,7 @@ for n, ln in enumerate(lines, 1):
     if not in_asm:
         for a in re.findall(r"a\[(\d+):(\d+)\]|\ba(\d+)\b", t):
             hi = int(a[1]) if a[1] else int(a[2])
-            if hi >= 144:
+            if hi >= 140:
                 bad_agpr.append((n, t))
     if in_asm and op.startswith(("global_load", "buffer_load")):
         used = set()
@@ -59,7 +59,7 @@ for n, ln in enumerate(lines, 1):
                 break
     hist.append((t, in_asm))
     hist = hist[-12:]
-print(f"{path}: compiler instructions touching a144+: {len(bad_agpr)}; unpadded VALU->SGPR->VMEM hazards: {len(hazards)}")
+print(f"{path}: compiler instructions touching a140+: {len(bad_agpr)}; unpadded VALU->SGPR->VMEM hazards: {len(hazards)}")
 for x in bad_agpr[:10]:
     print("  AGPR", x)
 for x in hazards[:10]:

@@ -26,3 +26,13 @@ for a in range(0, M, 32):
         blk = err[a:a + 32, b:b + 32]
         row.append("." if float(blk.max()) < 0.05 * float(ref.float().abs().mean()) + 1e-2 else "X")
     print(f"{a:5d} " + "".join(row))
+r = ref.float()
+for (a, b) in ((0, 0), (32, 0), (64, 128), (128, 0)):
+    if a < M:
+        q = (o[a:a + 4, b:b + 6] / r[a:a + 4, b:b + 6])
+        print("block", a, b, "out/ref:\n", q)
+        print(" out", o[a, b:b + 6], "\n ref", r[a, b:b + 6])
+# does a wrong row equal some other reference row?
+a = 0
+d = (r[:192, :64] - o[a, :64]).abs().sum(1)
+print("row", a, "closest ref row", int(d.argmin()), float(d.min()))
