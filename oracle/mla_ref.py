@@ -276,6 +276,62 @@ def get_mla_metadata(cache_seqlens, num_parts: int, page_size: int = PAGE_SIZE):
     return meta, num_splits
 
 
+def get_mla_metadata_positions(cache_seqlens, num_parts: int, page_size: int = PAGE_SIZE):
+    """The SAME partition as get_mla_metadata, stated the way csrc/mla_metadata.hip's one-pass kernel computes it (round 6): on the
+    cost axis C[r] = sum_{k<r} (tiles_k + FIXED_OVERHEAD) a part that starts at (req, tile) sits at x = C[req] + tile, ends at y = x + P, and
+    the next part starts at x' = max(y - FIXED_OVERHEAD, C[r']) with r' the first request the part does not finish (C[r' + 1] > y).  Every
+    candidate capacity walks ONCE and records (r', tile, split) per part; the rows and the split counts follow from the records of the
+    winning capacity without a second walk.  tests/test_oracle_golden.py checks it against get_mla_metadata on random batches."""
+    seqlens = [int(x) for x in cache_seqlens]
+    bs = len(seqlens)
+    OH = FIXED_OVERHEAD_TILES
+    ntiles = [((L + page_size - 1) // page_size) if L > 0 else 0 for L in seqlens]
+    C = [0]
+    for n in ntiles:
+        C.append(C[-1] + n + OH)
+    total = C[-1]
+    p_min = max((total + num_parts - 1) // num_parts, 1 + OH)
+    nt_max = max(ntiles, default=0)
+    split_cap = max(MIN_SPLIT_CAP, nt_max // PAGES_PER_SPLIT)
+    p_min = max(p_min, (nt_max + split_cap - 1) // split_cap + OH)
+
+    def walk(P):
+        r, p, split, y = 0, 0, 0, P
+        rec = [(0, 0, 0)]                         # (req, tile, split) at the start of part p
+        while r < bs and p < num_parts:
+            if C[r + 1] <= y:                     # the part finishes request r
+                r, split = r + 1, 0
+            else:                                 # the part closes inside (or in front of) request r
+                x = max(y - OH, C[r])
+                split += 1 if y - OH > C[r] else 0
+                p += 1
+                rec.append((r, x - C[r], split))
+                y = x + P
+        return r == bs, rec[:num_parts]
+
+    rec = None
+    for cand in range(p_min, p_min + 64):
+        ok, rc = walk(cand)
+        if ok:
+            rec = rc
+            break
+    if rec is None:
+        rec = walk(p_min + OH)[1]                  # the last part takes whatever is left
+    last = len(rec) - 1
+    meta = np.zeros((num_parts, META_W), dtype=np.int32)
+    touched = [1] * bs
+    for p in range(num_parts):
+        b = rec[p] if p <= last else (bs, 0, 0)
+        e = rec[p + 1] if p + 1 <= last else (bs, 0, 0)
+        meta[p, 0], meta[p, 1], meta[p, 4] = b[0], b[1], b[2]
+        meta[p, 2], meta[p, 3] = e[0], e[1]
+        if p <= last and e[0] > b[0]:
+            touched[b[0]] = b[2] + 1
+    num_splits = np.zeros(bs + 1, dtype=np.int32)
+    num_splits[1:] = np.cumsum(np.asarray(touched, dtype=np.int64)) if bs else []
+    return meta, num_splits
+
+
 # --------------------------------------------------------------------------------------
 # Bit-level statement of OUR kernel's arithmetic (csrc/mla_decode_fp8.hip) — NOT of the reference.
 # The exact oracle above bounds the end-to-end error (FP8 tolerance); this one pins the design:
