@@ -204,21 +204,9 @@ __device__ __forceinline__ void ldg_f32_async(float& dst, const unsigned voff, c
   asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
 
-// cache-policy bits of the refill (variant builds: -DFL_G3_DMA_POL=1 nt, 2 sc1, 3 sc0, 4 sc0 sc1)
-#if FL_G3_DMA_POL == 1
-#define FL_G3_DMA_AUX " nt"
-#elif FL_G3_DMA_POL == 2
-#define FL_G3_DMA_AUX " sc1"
-#elif FL_G3_DMA_POL == 3
-#define FL_G3_DMA_AUX " sc0"
-#elif FL_G3_DMA_POL == 4
-#define FL_G3_DMA_AUX " sc0 sc1"
-#else
-#define FL_G3_DMA_AUX
-#endif
 template <int OFF>
 __device__ __forceinline__ void fl_dma16_lds(const void* sbase, const unsigned voff, const int lds_slot) {
-  asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" FL_G3_DMA_AUX ::"s"(lds_slot), "v"(voff), "s"(sbase), "n"(OFF)
+  asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_slot), "v"(voff), "s"(sbase), "n"(OFF)
                : "memory", "m0", "scc");
 }
 
@@ -341,10 +329,6 @@ __global__ __launch_bounds__(256, 1) void grouped_gemm_fp8_big3_kernel(const Gem
     t.row_end = hi_row;
     t.w_base = gW + ((long long)e * p.N + t.n0 + 64 * wave) * p.K;
     t.a_base = gA + t.row0 * p.K;
-#ifdef FL_G3_L2HIT   // (bounding build, garbage results) every tile reads the first tile's operands: the same requests, all of them L2 hits
-    t.w_base = gW + (long long)(64 * wave) * p.K;
-    t.a_base = gA;
-#endif
     const unsigned m_last = (unsigned)(t.row_end - t.row0 - 1);   // rows beyond the group: clamped, never stored
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -427,41 +411,6 @@ __global__ __launch_bounds__(256, 1) void grouped_gemm_fp8_big3_kernel(const Gem
     //      are the next tile's stages 0 .. 2; without a next tile the last stage is fetched again into idle slots — one loop body, constant
     //      vmcnt counts), its sources wrun / arun / va_run, its ring slot lds_iss.  Piece k of this wave's share: 0..3 = W, 4..6 = A. ----
     auto issue_piece = [&](const int k) {
-#ifdef FL_G3_HALFW   // (bounding builds, garbage results) only the weight pieces / only the token pieces / every lane of a piece reads the same 16 bytes
-      if (k >= 4) return;
-#endif
-#ifdef FL_G3_HALFA
-      if (k < 4) return;
-#endif
-#ifdef FL_G3_LIN   // (bounding build, garbage results) the SAME bytes per wave and tile (its 64 weight rows x K, its 48 token rows x K), read as contiguous 1 KiB pieces
-      {
-        const uint8_t* wl = cur.w_base + ((wrun - cur.w_base) & 0x1fff) * 64;   // (masked: the pointer may already be the next tile's)
-        const uint8_t* al = cur.a_base + (long long)48 * wave * p.K + ((arun - cur.a_base) & 0x1fff) * 48;
-        const unsigned vl = (unsigned)lane * 16u;
-        switch (k) {
-          case 0: fl_dma16_lds<0>(wl, vl, lds_iss_w); break;
-          case 1: fl_dma16_lds<1024>(wl, vl + 1024u, lds_iss_w); break;
-          case 2: fl_dma16_lds<2048>(wl, vl + 2048u, lds_iss_w); break;
-          case 3: fl_dma16_lds<3072>(wl, vl + 3072u, lds_iss_w); break;
-          case 4: fl_dma16_lds<0>(al, vl, lds_iss_a); break;
-          case 5: fl_dma16_lds<1024>(al, vl + 1024u, lds_iss_a); break;
-          default: fl_dma16_lds<2048>(al, vl + 2048u, lds_iss_a); break;
-        }
-        return;
-      }
-#endif
-#ifdef FL_G3_BCAST
-      switch (k) {
-        case 0: fl_dma16_lds<0>(wrun, 0u, lds_iss_w); break;
-        case 1: fl_dma16_lds<1024>(wrun, 0u, lds_iss_w); break;
-        case 2: fl_dma16_lds<2048>(wrun, 0u, lds_iss_w); break;
-        case 3: fl_dma16_lds<3072>(wrun, 0u, lds_iss_w); break;
-        case 4: fl_dma16_lds<0>(arun, 0u, lds_iss_a); break;
-        case 5: fl_dma16_lds<1024>(arun, 0u, lds_iss_a); break;
-        default: fl_dma16_lds<2048>(arun, 0u, lds_iss_a); break;
-      }
-      return;
-#endif
       switch (k) {
         case 0: fl_dma16_lds<0>(wrun, vw4[0], lds_iss_w); break;
         case 1: fl_dma16_lds<1024>(wrun, vw4[1], lds_iss_w); break;
@@ -606,12 +555,6 @@ __global__ __launch_bounds__(256, 1) void grouped_gemm_fp8_big3_kernel(const Gem
         if (STAMP) ts[(ODD ? 13 : 0) + s] = __builtin_readcyclecounter();
 #endif
         if (j < NJT) mfma3(acc[i][j], cs, i, j, e8[j], FIRST && !ODD);
-#ifdef FL_G3_SKEW   // (experiment) wave w starts its fillers FL_G3_SKEW x 16 w cycles behind the barrier: the four waves' LDS-DMA pieces of a slot do not meet at the texture addresser
-        if (s == 2) {
-          if (wave & 1) { for (int q = 0; q < FL_G3_SKEW; ++q) asm volatile("s_nop 15"); }
-          if (wave & 2) { for (int q = 0; q < 2 * FL_G3_SKEW; ++q) asm volatile("s_nop 15"); }
-        }
-#endif
         // fragments of the next half step
 #pragma unroll
         for (int f = 0; f < 7; ++f)
@@ -791,9 +734,6 @@ int fl_gemm_launch_big3(const GemmParams& p_in, const void* A, const float* As, 
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && fl_device_cu_count(dev, &cus) == FL_OK && cus > 0 && grid > cus) grid = cus;
   }
-#ifdef FL_G3_GRIDENV   // (experiment builds) FLUENT_G3_GRID caps the number of workgroups: per-CU rate against the number of busy CUs
-  if (const char* e = getenv("FLUENT_G3_GRID")) { const long long g = atoll(e); if (g > 0 && g < grid) grid = g; }
-#endif
   grouped_gemm_fp8_big3_kernel<<<dim3((unsigned)grid), dim3(256), 0, stream>>>(p, (const uint8_t*)A, As, (const uint8_t*)W, Ws, group_meta);
   FL_CHECK_LAUNCH("grouped_gemm_fp8_big3_kernel");
   return FL_OK;
