@@ -181,38 +181,49 @@ __global__ __launch_bounds__(256) void mla_metadata_fast_kernel(const int32_t* _
     // lane l walks capacity p_min + l.  State: r = first unfinished request, y = end of the open part, w0..w2 = C[r..r+2], ld = C[r + 3] in
     // flight (issued at the end of the previous iteration, consumed at the end of this one: the LDS latency sits beside the iteration's VALU
     // work).  SELECTS ONLY (a divergent branch per event costs more than the whole body: hipcc's exec-mask blocks wait for their LDS read), and
-    // ONE unconditional store per event: the would-be start of part p + 1 goes to row p + 1 every iteration — the iteration that closes part p
-    // writes it last.  ~20 VALU instructions per event.
+    // ONE unconditional store per event: the would-be
+    // start of part p + 1 goes to row p + 1 every iteration — the iteration that closes part p writes it last.  A walk that has finished its
+    // requests keeps closing empty parts at positions >= total (C[bs + 1] = "never reached" stops the advance): a row holds a real part start
+    // iff its position is < total, and the capacity fits iff row num_parts does not.  ~18 instructions per event.
     const int P = p_min + lane;
     int r = 0, p = 0, y = P;
     int w0 = 0, w1 = cost[1], w2 = cost[2], ld = cost[3];
     xs[lane] = 0;
-    bool live = bs > 0;
-    while (__any(live)) {
-      const bool adv = w1 <= y;                                  // the open part finishes request r
-      const int yo = y - kFixedOverhead;
-      const int x = yo > w0 ? yo : w0;
-      const bool step = live & adv, close = live & !adv;
-      xs[(p + 1) * 64 + lane] = x;
-      r = step ? r + 1 : r;
-      w0 = step ? w1 : w0;
-      w1 = step ? w2 : w1;
-      w2 = step ? ld : w2;
-      p = close ? p + 1 : p;
-      y = close ? x + P : y;
-      ld = cost[r + 3];                                          // (r <= bs: inside the padding)
-      live = (r < bs) & (p < num_parts);
+    // (the exit test — every lane has finished its requests or closed num_parts parts — costs a ballot: once per eight events)
+    bool busy = bs > 0;
+    while (__any(busy)) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool adv = w1 <= y;                                // the open part finishes request r
+        const int yo = y - kFixedOverhead;
+        const int x = yo > w0 ? yo : w0;
+        const int row = p + 1 < num_parts + 1 ? p + 1 : num_parts + 1;
+        xs[row * 64 + lane] = x;
+        r = adv ? r + 1 : r;
+        w0 = adv ? w1 : w0;
+        w1 = adv ? w2 : w1;
+        w2 = adv ? ld : w2;
+        p = adv ? p : p + 1;
+        y = adv ? y : x + P;
+        ld = cost[r + 3];                                        // (r <= bs: inside the padding)
+      }
+      busy = r < bs && p < num_parts;
     }
-    const bool ok = r >= bs;
+    // rows 0 .. min(p, num_parts) of a lane are exact; it fits iff it finished and row num_parts (if it got that far) is not a real part start
+    const bool ok = bs <= 0 || (r >= bs && (p < num_parts || xs[num_parts * 64 + lane] >= total));
     const unsigned long long okmask = __ballot(ok);
     const int win = okmask ? __builtin_ctzll(okmask) : kFixedOverhead;   // (fallback: capacity p_min + FIXED_OVERHEAD, the last part takes the rest)
-    const int p_end = __shfl(p, win);
-    if (lane == 0) { s_win[0] = win; s_win[1] = p_end < num_parts ? p_end : num_parts - 1; }
+    const int p_win = __shfl(p, win);
+    if (lane == 0) { s_win[0] = win; s_win[1] = p_win < num_parts - 1 ? p_win : num_parts - 1; }
   }
   __syncthreads();
   // part p of the winning capacity starts at x_p: request = the last r with C[r] <= x_p, tile = x_p - C[r]; pieces of that request in earlier
   // parts = p - (the last part q with x_q <= C[r]).  Two binary searches per part, all parts at once.
-  const int win = s_win[0], last = bs > 0 ? s_win[1] : -1;
+  const int win = s_win[0];
+  int real = 0;                               // part starts of the winning walk that lie inside the batch (positions < total)
+  const int p_hi = s_win[1];                  // rows beyond the winner's last close were never written
+  for (int p0 = 0; p0 < num_parts; p0 += 256) real += __syncthreads_count(p0 + tid <= p_hi && bs > 0 && xs[(p0 + tid) * 64 + win] < total);
+  const int last = real - 1;
   auto decode = [&](const int p, int& req, int& tile, int& split) {
     const int x = xs[p * 64 + win];
     int lo = 0, hi = bs - 1;                 // C[0] = 0 <= x; x < C[bs] for every opened part

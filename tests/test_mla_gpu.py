@@ -172,7 +172,8 @@ def test_decode_with_the_query_quantised_in_its_prologue_is_bit_identical(fm, bs
 
 # ---------------------------------------------------------------- K3: scheduler, bit-exact vs its Python statement
 @pytest.mark.parametrize("lens,rows", [([4096] * 128, 128), ([1] * 160, 16), ([0, 5, 200, 0, 9000], 128),
-                                       ([16384], 64), ([63, 64, 65, 4095, 4097] * 7, 512)])
+                                       ([16384], 64), ([63, 64, 65, 4095, 4097] * 7, 512), ([4096] * 128, 16), ([700] * 1000, 16),
+                                       ([0] * 40 + [130] * 3 + [0] * 9, 128), ([8192] * 256, 16), ([1], 128), ([65536], 16)])
 def test_get_mla_metadata_bit_exact(fm, lens, rows):
     seq = torch.tensor(lens, dtype=torch.int32, device=dev())
     meta, ns = fm.get_mla_metadata(seq, rows, 1)

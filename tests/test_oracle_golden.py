@@ -219,3 +219,22 @@ def test_ep_scatter_gather_oracle_exact_vs_reference_triton_golden():
     assert np.array_equal(m_idx, g["m_idx"]) and np.array_equal(oidx, g["oidx"])
     got = ep_ref.ep_gather(bf16_to_f32(g["y"]), g["topk"], g["w"], g["oidx"])
     assert np.array_equal(got, g["gathered"])
+
+
+def test_metadata_positions_statement_equals_the_two_walk_statement():
+    """K3: the cost-axis formulation the one-walk kernel implements (mla_ref.get_mla_metadata_positions) is the SAME partition as
+    mla_ref.get_mla_metadata on uniform, ragged, empty, zero-length and oversubscribed batches (fixed seed)."""
+    import random
+    rnd = random.Random(7)
+    cases = [([4096] * 128, 128), ([4096] * 128, 256), ([1] * 160, 256), ([0, 5, 200, 0, 9000], 128), ([16384], 128), ([], 16), ([0], 8),
+             ([0, 0, 0], 4), ([100000] * 3, 4), ([63, 64, 65, 4095, 4097] * 7, 32)]
+    for _ in range(400):
+        bs = rnd.choice([1, 2, 3, 7, 16, 50, 128, 300])
+        mx = rnd.choice([1, 64, 130, 1000, 5000, 20000])
+        lens = [rnd.choice([0, rnd.randint(0, mx), mx]) for _ in range(bs)]
+        if rnd.random() < 0.3:
+            lens = [mx] * bs
+        cases.append((lens, rnd.choice([1, 2, 3, 8, 32, 64, 128, 256])))
+    for lens, parts in cases:
+        a, b = mla_ref.get_mla_metadata(lens, parts), mla_ref.get_mla_metadata_positions(lens, parts)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (lens[:8], len(lens), parts)

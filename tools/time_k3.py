@@ -7,7 +7,7 @@ import flash_mla_fp8 as fm
 
 dev = torch.device("cuda:0")
 out = {}
-for bs, seq, rows in ((128, 4096, 128), (256, 8192, 16), (32, 8192, 128), (2048, 1024, 16)):
+for bs, seq, rows in ((1, 4096, 128), (8, 4096, 128), (128, 4096, 128), (256, 8192, 16), (32, 8192, 128), (2048, 1024, 16)):
     g = torch.Generator().manual_seed(bs)
     sl = (torch.randint(seq // 2, seq + 1, (bs,), generator=g, dtype=torch.int32)).to(dev)
     fm.get_mla_metadata(sl, rows, 1); torch.cuda.synchronize()
