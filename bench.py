@@ -32,6 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float
 
 
 class GpuSampler:
+    matched = False   # the hwmon node was chosen by the device's PCI address
     """~10 Hz sampler of shader clock and socket power around a measured loop (VERDICT r5 item 3: the power-cap argument belongs in the
     driver's record).  Sources, first that answers: the amdgpu hwmon files of the device (no subprocess: freq1_input Hz, power1_average /
     power1_input uW, power1_cap uW), then `rocm-smi --showpower --showclocks`.  Every field is None when nothing answers — the headline
@@ -46,6 +47,8 @@ class GpuSampler:
 
     @staticmethod
     def _find_hwmon(index):
+        """hwmon directory of HIP device `index`: the drm card whose PCI address is the device's (a box may expose the sysfs nodes of GPUs this
+        process cannot open: "the first card" reads somebody else's idle — or busy — chip); without a PCI match, the first candidate."""
         import glob
         cands = []
         for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
@@ -54,10 +57,19 @@ class GpuSampler:
             for hm in sorted(glob.glob(os.path.join(card, "device/hwmon/hwmon*"))):
                 if os.path.exists(os.path.join(hm, "freq1_input")) and (os.path.exists(os.path.join(hm, "power1_average"))
                                                                           or os.path.exists(os.path.join(hm, "power1_input"))):
-                    cands.append(hm)
+                    cands.append((os.path.basename(os.path.realpath(os.path.join(card, "device"))).lower(), hm))
         if not cands:
             return None
-        return cands[index] if index < len(cands) else cands[0]
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            for addr, hm in cands:
+                if addr.startswith(want):
+                    GpuSampler.matched = True
+                    return hm
+        except Exception:
+            pass
+        return cands[index][1] if index < len(cands) else cands[0][1]
 
     @staticmethod
     def _rd(path):
@@ -113,7 +125,8 @@ class GpuSampler:
         pw = [p for _, p in self.samples if p]
         return {"sclk_mhz_mean": round(sum(sc) / len(sc)) if sc else None, "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None,
                 "power_w_max": round(max(pw), 1) if pw else None, "power_cap_w": round(self.cap, 1) if self.cap else None,
-                "samples": len(self.samples), "source": "hwmon" if self.hw is not None else "rocm-smi"}
+                "samples": len(self.samples),
+                "source": ("hwmon (PCI address of the device)" if GpuSampler.matched else "hwmon (first card: no PCI match)") if self.hw is not None else "rocm-smi"}
 
 
 def sampled_loop(fn, seconds=2.5, chunk=4, index=0):

@@ -35,11 +35,15 @@ typedef void* fl_stream_t;
 #define FL_KV_FP8_576 1       /* one fp8 [.,576] tensor, descale scalars */
 #define FL_KV_BF16_576 2      /* one bf16 [.,576] tensor */
 
-/* ABI version of THIS header.  A binding checks fl_version() == FL_ABI_VERSION once after loading the library, and every argument
- * struct carries its own size (`struct_bytes`, first field) so that a caller compiled against another layout is refused with
- * FL_ERR_INVALID instead of being read past its end.  101: FlMlaDecodeArgs gained struct_bytes (first) and block_table_cols (last);
- * fl_topk_gate added. */
-#define FL_ABI_VERSION 101
+/* ABI version of THIS header.  A binding checks fl_version() == FL_ABI_VERSION once after loading the library: that check covers EVERY
+ * argument struct below.  FlMlaDecodeArgs — the one struct that has grown so far — additionally carries its own size (`struct_bytes`, first
+ * field): a caller compiled against another layout of it is refused with FL_ERR_INVALID instead of being read past its end.  The other
+ * argument structs (FlGroupedGemmArgs, FlRopeArgs, FlMlaAbsorbArgs ...) have no size field and are read as this header lays them out.
+ * 101: FlMlaDecodeArgs gained struct_bytes (FIRST field: every later field moved — a C caller built against 100 must be recompiled) and
+ *      block_table_cols (last); fl_topk_gate added.
+ * 102: additive — fl_fused_add_rmsnorm_offset (GemmaRMSNorm: the 1 added in fp32), fl_mla_set_merge_timeout (+ the in-kernel split merge
+ *      reports a timeout through the next fl_mla_decode call); no struct changed. */
+#define FL_ABI_VERSION 102
 const char* fl_last_error(void);
 int fl_version(void);
 /* number of compute units of HIP device `device` (host query, cached) */
@@ -154,6 +158,10 @@ typedef struct FlMlaDecodeArgs {
 } FlMlaDecodeArgs;
 
 int fl_mla_decode(const FlMlaDecodeArgs* args, fl_stream_t stream);
+/* Budget of the in-kernel split merge's wait for a request's other pieces (default 2 s; env FLUENT_MLA_MERGE_TIMEOUT_S).  A merger that gives up
+ * writes NaN into the request's rows and LSEs AND reports through a host-mapped word: the NEXT fl_mla_decode call returns FL_ERR_LAUNCH
+ * (fl_last_error names the workgroup).  Synchronises the device (hipMemcpyToSymbol): call it outside captures. */
+int fl_mla_set_merge_timeout(double seconds);
 /* Sizes of the two workspaces above for a launch of this shape (the partial rows are bf16 or f32 depending on the
  * mapping the shape dispatches to; allocate exactly this much, e.g. from the graph's memory pool). */
 int fl_mla_workspace_bytes(int kv_format, int bs, int s_q, int h_q, int num_parts, int64_t* o_accum_bytes,
@@ -215,6 +223,11 @@ int fl_fused_add_rmsnorm(const void* x, int num_pieces, int64_t piece_stride /*e
                          const void* residual_in, const void* gamma, float eps, int64_t T, int H, void* residual_out,
                          void* norm_out, void* quant_out, float* scale_out, int64_t s_stride_t, int64_t s_stride_g,
                          fl_stream_t stream);
+/* The same with norm_out = bf16(v * rsqrt(..) * (gamma + gamma_offset)), the offset added in fp32: GemmaRMSNorm (layernorm.py:209-233,
+ * gamma_offset = 1).  x / residual_in may alias norm_out / residual_out (flashinfer's in-place fused_add_rmsnorm). */
+int fl_fused_add_rmsnorm_offset(const void* x, int num_pieces, int64_t piece_stride /*elements*/, const void* add_in,
+                                const void* residual_in, const void* gamma, float gamma_offset, float eps, int64_t T, int H,
+                                void* residual_out, void* norm_out, fl_stream_t stream);
 /* C7 (layernorm.py:305-359 <- models/deepseek_v2.py:799-807): dual RMSNorm over gathered rows ag bf16 [T, D]:
  * cols [0, q_rank) -> x_norm_out [T, q_rank] (+ optional 1x128 fp8 quant), cols [q_rank, q_rank+kv_rank) in place. */
 int fl_dual_rmsnorm(void* ag, int64_t T, int D, int q_rank, int kv_rank, const void* gamma_q, const void* gamma_kv,

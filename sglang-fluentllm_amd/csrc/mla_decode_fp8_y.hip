@@ -47,7 +47,12 @@ static_assert(4 * 32 * kStgBytes <= kRingSlots * kSlotBytes, "epilogue staging f
 // waves: q(W), v(Wd), one per SIMD) for at most 32 rows — the TP8 shard's H = 16.  The 32 LDS-DMA pieces of a page are shared by the
 // 2 NRT PV waves: 8 or 16 pieces of 1 KiB per PV wave and page.
 template <int NRT> constexpr int pieces_per_wave() { return kDmaNopePerTile / (2 * NRT); }
-constexpr unsigned long long kMergeTimeoutTicks = 200000000ull;    // 2 s of the 100 MHz wall clock: budget of the in-kernel split merge's poll
+// Budget of the in-kernel split merge's poll, in ticks of the 100 MHz wall clock (default 2 s; fl_mla_set_merge_timeout / FLUENT_MLA_MERGE_TIMEOUT_S),
+// and the host-mapped word a merger that gives up reports to (0 = none yet): the outputs of that launch are NaN AND the next fl_mla_decode call
+// on the host returns FL_ERR_LAUNCH with the part's index (a timeout must not stay a silent wrong answer).  Device globals, read on the
+// cold path only: nothing is added to the kernel's arguments.
+__device__ unsigned long long g_merge_timeout_ticks = 200000000ull;
+__device__ unsigned* g_merge_err = nullptr;
 
 // (The experiment switches of rounds 2-4 — mid-step barrier, dual accumulate chain, lagged reference, tail loads inside the chain,
 //  L2 prefetch touches, DMA placement, the garbage-result bounding builds — live in probes/r05_k1_lab_switches.patch.txt with
@@ -949,8 +954,12 @@ __global__ __launch_bounds__(256 * NRT) void mla_decode_y_kernel(
           while (((arrived >> sh) & 0xffff) != tgt) {
             __builtin_amdgcn_s_sleep(2);
             arrived = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (wall_clock64() - t_poll > kMergeTimeoutTicks) { merge_timed_out = true; break; }
+            if (wall_clock64() - t_poll > g_merge_timeout_ticks) { merge_timed_out = true; break; }
           }
+        }
+        if (merge_timed_out && lane == 0) {
+          unsigned* e = g_merge_err;
+          if (e != nullptr) __hip_atomic_store(e, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         FL_T(7);   // merging piece: wait for the other pieces
         if (lane == 0) {   // the last of the four PV waves past the poll puts the counter back (the same metadata serves every layer's launch)
@@ -1090,7 +1099,51 @@ __global__ __launch_bounds__(256 * NRT) void mla_decode_y_kernel(
 
 }  // namespace
 
+namespace {
+unsigned* g_merge_err_host = nullptr;   // host side of the mapped error word
+void merge_err_init(hipStream_t stream) {
+  static bool tried = false;
+  if (tried) return;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;   // (not under capture: first eager call)
+  tried = true;
+  void *hp = nullptr, *dp = nullptr;
+  if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipGetLastError(); return; }
+  *(volatile unsigned*)hp = 0u;
+  unsigned* dpu = (unsigned*)dp;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_merge_err), &dpu, sizeof(dpu)) != hipSuccess) { (void)hipGetLastError(); return; }
+  g_merge_err_host = (unsigned*)hp;
+  if (const char* e = getenv("FLUENT_MLA_MERGE_TIMEOUT_S")) {
+    const double sec = atof(e);
+    if (sec > 0 && sec <= 3600) {
+      const unsigned long long ticks = (unsigned long long)(sec * 1e8);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_merge_timeout_ticks), &ticks, sizeof(ticks));
+    }
+  }
+}
+}  // namespace
+
+extern "C" int fl_mla_set_merge_timeout(double seconds) {
+  FL_CHECK_ARG(seconds > 0 && seconds <= 3600, "fl_mla_set_merge_timeout: %g s (0 < s <= 3600)", seconds);
+  const unsigned long long ticks = (unsigned long long)(seconds * 1e8);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_merge_timeout_ticks), &ticks, sizeof(ticks)) != hipSuccess) {
+    fl_set_error("fl_mla_set_merge_timeout: hipMemcpyToSymbol failed");
+    return FL_ERR_LAUNCH;
+  }
+  return FL_OK;
+}
+
 int fl_mla_decode_fp8_y_impl(const FlMlaDecodeArgs* a, const Params& p_in, hipStream_t stream) {
+  merge_err_init(stream);
+  if (g_merge_err_host != nullptr) {
+    const unsigned w = *(volatile unsigned*)g_merge_err_host;
+    if (w != 0u) {
+      *(volatile unsigned*)g_merge_err_host = 0u;
+      fl_set_error("fl_mla_decode: the in-kernel split merge of an EARLIER launch gave up waiting for a request's other pieces (workgroup %u): that "
+                   "launch wrote NaN into the request's rows and LSEs; its scheduler metadata must be rebuilt (fl_mla_get_metadata) before reuse", w - 1u);
+      return FL_ERR_LAUNCH;
+    }
+  }
   Params p = p_in;
   const int nrt = p.rows > 32 ? 2 : 1;   // row tiles per workgroup: 64-row workgroups of 8 waves, or 32-row workgroups of 4 (TP8 shard: H = 16)
   p.row_groups = (p.rows + 32 * nrt - 1) / (32 * nrt);

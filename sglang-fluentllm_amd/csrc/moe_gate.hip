@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__
   if (lane < topk) {
     const bool padded = num_token_non_padded != nullptr && t >= (long long)*num_token_non_padded;
     w_out[t * topk + lane] = my_w / sum * out_scale;
-    id_out[t * topk + lane] = padded ? -1 : my_id;
+    // (fewer finite candidates than topk — NaN logits, -inf biases: the slot gets weight 0 and a VALID id (its own slot number), never an
+    //  index a consumer could read out of bounds with; padded rows keep the reference's -1)
+    id_out[t * topk + lane] = padded ? -1 : (my_id >= 0 ? my_id : lane);
   }
 }
 
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void topk_gate_kernel(const float* __restrict_
   }
   if (lane < topk) {
     w_out[t * topk + lane] = (renorm ? my_w / sum : my_w) * scale;
-    id_out[t * topk + lane] = my_id;
+    id_out[t * topk + lane] = my_id >= 0 ? my_id : lane;   // (no finite candidate left: weight 0, a valid id)
   }
 }
 }  // namespace

@@ -17,17 +17,16 @@ using namespace fl_norm;
 // One WORKGROUP (4 waves) per row; x = sum of num_pieces pieces (piece w at x + w*piece_stride).  A decode step has a few
 // hundred rows: one wave per row leaves all but one wave slot per CU empty and serialises 14 dependent 16-B accesses per
 // lane (measured 32 us for 256 x 7168); the row work itself is fl_norm::add_rmsnorm_row (norm_row.h).
-__global__ __launch_bounds__(256) void add_rmsnorm_kernel(const uint16_t* __restrict__ x, int num_pieces,
-                                                          long long piece_stride, const uint16_t* __restrict__ add_in,
-                                                          const uint16_t* __restrict__ residual_in,
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(const uint16_t* x, int num_pieces, long long piece_stride,
+                                                          const uint16_t* __restrict__ add_in, const uint16_t* residual_in,
                                                           const uint16_t* __restrict__ gamma, float eps, long long T, int H,
-                                                          uint16_t* __restrict__ residual_out, uint16_t* __restrict__ norm_out,
+                                                          uint16_t* residual_out, uint16_t* norm_out,
                                                           uint8_t* __restrict__ quant_out, float* __restrict__ scale_out,
-                                                          long long ss_t, long long ss_g) {
+                                                          long long ss_t, long long ss_g, float gamma_offset) {
   __shared__ float wsum[4];
   const long long row = blockIdx.x;
   add_rmsnorm_row(x + row * H, num_pieces, piece_stride, add_in, residual_in, gamma, eps, row, H, residual_out, norm_out,
-                  quant_out, scale_out, ss_t, ss_g, wsum);
+                  quant_out, scale_out, ss_t, ss_g, wsum, gamma_offset);
 }
 
 // C7: dual RMSNorm over the gathered [T, D] rows: cols [0, q_rank) -> x_norm_out (separate tensor, optional fp8 quant),
@@ -46,22 +45,36 @@ __global__ __launch_bounds__(256) void dual_rmsnorm_kernel(uint16_t* __restrict_
 
 }  // namespace
 
-extern "C" int fl_fused_add_rmsnorm(const void* x, int num_pieces, int64_t piece_stride, const void* add_in,
-                                    const void* residual_in, const void* gamma, float eps, int64_t T, int H,
-                                    void* residual_out, void* norm_out, void* quant_out, float* scale_out,
-                                    int64_t s_stride_t, int64_t s_stride_g, fl_stream_t stream) {
+static int launch_add_rmsnorm(const void* x, int num_pieces, int64_t piece_stride, const void* add_in, const void* residual_in,
+                              const void* gamma, float eps, int64_t T, int H, void* residual_out, void* norm_out, void* quant_out,
+                              float* scale_out, int64_t s_stride_t, int64_t s_stride_g, float gamma_offset, fl_stream_t stream) {
   if (T == 0) return FL_OK;   // (a rank without token rows — T < world — passes empty tensors: null data pointers)
   FL_CHECK_ARG(x && num_pieces >= 1 && T >= 0, "fl_fused_add_rmsnorm: bad arguments");
   FL_CHECK_ARG(gamma != nullptr || (norm_out == nullptr && quant_out == nullptr), "fl_fused_add_rmsnorm: norm needs gamma");
   FL_CHECK_ARG(H > 0 && H % 8 == 0 && H <= kMaxChunks * 512, "fl_fused_add_rmsnorm: H=%d (need H %% 8 == 0, H <= 8192)", H);
   FL_CHECK_ARG(quant_out == nullptr || (scale_out != nullptr && H % 128 == 0), "fl_fused_add_rmsnorm: quant needs scales, H %% 128 == 0");
-  if (T == 0) return FL_OK;
   add_rmsnorm_kernel<<<dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream>>>(
       (const uint16_t*)x, num_pieces, piece_stride, (const uint16_t*)add_in, (const uint16_t*)residual_in,
       (const uint16_t*)gamma, eps, T, H, (uint16_t*)residual_out, (uint16_t*)norm_out, (uint8_t*)quant_out, scale_out,
-      s_stride_t, s_stride_g);
+      s_stride_t, s_stride_g, gamma_offset);
   FL_CHECK_LAUNCH("fl_fused_add_rmsnorm");
   return FL_OK;
+}
+
+extern "C" int fl_fused_add_rmsnorm(const void* x, int num_pieces, int64_t piece_stride, const void* add_in,
+                                    const void* residual_in, const void* gamma, float eps, int64_t T, int H,
+                                    void* residual_out, void* norm_out, void* quant_out, float* scale_out,
+                                    int64_t s_stride_t, int64_t s_stride_g, fl_stream_t stream) {
+  return launch_add_rmsnorm(x, num_pieces, piece_stride, add_in, residual_in, gamma, eps, T, H, residual_out, norm_out, quant_out,
+                            scale_out, s_stride_t, s_stride_g, 0.f, stream);
+}
+
+// the Gemma form (layernorm.py:209-233: x * rsqrt(..) * (1 + w), the 1 added in fp32): same kernel, gamma_offset = 1
+extern "C" int fl_fused_add_rmsnorm_offset(const void* x, int num_pieces, int64_t piece_stride, const void* add_in,
+                                           const void* residual_in, const void* gamma, float gamma_offset, float eps, int64_t T, int H,
+                                           void* residual_out, void* norm_out, fl_stream_t stream) {
+  return launch_add_rmsnorm(x, num_pieces, piece_stride, add_in, residual_in, gamma, eps, T, H, residual_out, norm_out, nullptr, nullptr,
+                            0, 0, gamma_offset, stream);
 }
 
 extern "C" int fl_dual_rmsnorm(void* ag, int64_t T, int D, int q_rank, int kv_rank, const void* gamma_q,

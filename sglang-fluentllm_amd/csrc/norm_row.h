@@ -48,12 +48,15 @@ constexpr int kRowChunks = 4;    // chunks of 256 threads x 8 elements per threa
 // One WORKGROUP (256 threads) per row; H % 8 == 0, H <= 8192.  The row of piece w is at xrow + w*piece_stride; add_in /
 // residual_in / the outputs are indexed by `row`.  `wsum`: 4 floats of LDS.  A thread owns <= 4 groups of 8 elements,
 // every load of the row is issued before the first use, and the four waves meet once for the sum of squares.
-__device__ __forceinline__ void add_rmsnorm_row(const uint16_t* __restrict__ xrow, const int num_pieces, const long long piece_stride,
-                                                const uint16_t* __restrict__ add_in, const uint16_t* __restrict__ residual_in,
+// (xrow / residual_in may ALIAS norm_out / residual_out — flashinfer's in-place fused_add_rmsnorm: no __restrict__ on those four; every thread
+//  reads its own elements of a row before it writes them.  gamma_offset: 1.0 for the Gemma form x * (1 + w), added in fp32 as the reference does.)
+__device__ __forceinline__ void add_rmsnorm_row(const uint16_t* xrow, const int num_pieces, const long long piece_stride,
+                                                const uint16_t* __restrict__ add_in, const uint16_t* residual_in,
                                                 const uint16_t* __restrict__ gamma, const float eps, const long long row, const int H,
-                                                uint16_t* __restrict__ residual_out, uint16_t* __restrict__ norm_out,
+                                                uint16_t* residual_out, uint16_t* norm_out,
                                                 uint8_t* __restrict__ quant_out, float* __restrict__ scale_out,
-                                                const long long ss_t, const long long ss_g, float* __restrict__ wsum) {
+                                                const long long ss_t, const long long ss_g, float* __restrict__ wsum,
+                                                const float gamma_offset = 0.f) {
   const int tid = threadIdx.x;
   float v[kRowChunks][8];
   uint4 gr[kRowChunks];
@@ -112,6 +115,10 @@ __device__ __forceinline__ void add_rmsnorm_row(const uint16_t* __restrict__ xro
     if (col < H) {
       float g[8], y[8];
       unpack8(gr[c], g);
+      if (gamma_offset != 0.f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] += gamma_offset;
+      }
       const uint32_t p0 = fl_pack_bf16(v[c][0] * rinv * g[0], v[c][1] * rinv * g[1]);
       const uint32_t p1 = fl_pack_bf16(v[c][2] * rinv * g[2], v[c][3] * rinv * g[3]);
       const uint32_t p2 = fl_pack_bf16(v[c][4] * rinv * g[4], v[c][5] * rinv * g[5]);

@@ -6,7 +6,7 @@ import torch
 LIB_PATH = os.environ.get("FLUENT_MI355_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                                             "libfluent_mi355.so")
 
-ABI_VERSION = 101   # include/fluent_mi355.h: FL_ABI_VERSION
+ABI_VERSION = 102   # include/fluent_mi355.h: FL_ABI_VERSION
 _c_void_p = ctypes.c_void_p
 _i32p = ctypes.c_void_p
 _f32p = ctypes.c_void_p

@@ -67,6 +67,8 @@ class HipNormOps:
         vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
         lib.fl_fused_add_rmsnorm.argtypes = [vp, i32, i64, vp, vp, vp, f32, i64, i32, vp, vp, vp, vp, i64, i64, vp]
         lib.fl_fused_add_rmsnorm.restype = i32
+        lib.fl_fused_add_rmsnorm_offset.argtypes = [vp, i32, i64, vp, vp, vp, f32, f32, i64, i32, vp, vp, vp]
+        lib.fl_fused_add_rmsnorm_offset.restype = i32
         lib.fl_dual_rmsnorm.argtypes = [vp, i64, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp, i64, i64, vp]
         lib.fl_dual_rmsnorm.restype = i32
 
@@ -74,13 +76,20 @@ class HipNormOps:
     def _p(t):
         return None if t is None else t.data_ptr()
 
-    def add_rmsnorm(self, pieces, add_in, residual_in, gamma, eps, residual_out, norm_out, quant_out, scale_out):
-        """pieces [W, T, H] bf16 contiguous."""
+    def add_rmsnorm(self, pieces, add_in, residual_in, gamma, eps, residual_out, norm_out, quant_out, scale_out, gamma_offset=0.0):
+        """pieces [W, T, H] bf16 contiguous.  gamma_offset != 0: norm_out uses (gamma + gamma_offset), added in fp32 (GemmaRMSNorm)."""
         W, T, H = pieces.shape
         if T == 0:
             return   # a rank without token rows (T < world): nothing to compute; the collectives around this call still ran
         for t in (pieces, add_in, residual_in, gamma, residual_out, norm_out):
             assert t is None or (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()), "bf16 contiguous CUDA tensors"
+        if gamma_offset != 0.0:
+            assert quant_out is None and scale_out is None, "the offset form has no fused quantisation"
+            self._check(self._lib.fl_fused_add_rmsnorm_offset(pieces.data_ptr(), W, T * H, self._p(add_in), self._p(residual_in),
+                                                              self._p(gamma), float(gamma_offset), float(eps), T, H,
+                                                              self._p(residual_out), self._p(norm_out), self._stream(pieces.device)),
+                        "fl_fused_add_rmsnorm_offset")
+            return
         sst, ssg = (scale_out.stride(0), scale_out.stride(1)) if scale_out is not None else (0, 0)
         self._check(self._lib.fl_fused_add_rmsnorm(pieces.data_ptr(), W, T * H, self._p(add_in), self._p(residual_in),
                                                    self._p(gamma), float(eps), T, H, self._p(residual_out),

@@ -16,6 +16,7 @@ lib.fl_kv_move.restype = _i
 lib.fl_kv_move_staged.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp]
 lib.fl_kv_move_staged.restype = _i
 _MAX_ROWS_IN_REGISTERS = 8192   # csrc/kv_move.hip: kCap
+_STAGING_MAX_BYTES = 4 << 30   # staged path (> 8192 rows): upper bound of the gather area of ONE move (61 layers x 656 B x 100 k rows = 4 GB)
 
 
 class KVMoveTable:
@@ -44,7 +45,7 @@ class KVMoveTable:
         for rb in row_bytes[:-1]:
             prefix.append(prefix[-1] + rb)
         self.row_prefix = torch.tensor(prefix, dtype=torch.int64).to(dev)   # staging layout of the > 8192-row path
-        self._staging = None
+        self._staging = {}   # stream -> staging area of the > 8192-row path
 
     def move(self, tgt_loc, src_loc):
         """rows tgt_loc[i] <- src_loc[i] in every buffer; sets may overlap (all reads precede all writes)"""
@@ -61,12 +62,23 @@ class KVMoveTable:
                                  t.data_ptr(), s.data_ptr(), n, self.num_slots, stream_ptr(dev)), "fl_kv_move")
             return
         # more rows than one workgroup holds between its reads and its writes: gather every source row into a staging area, then scatter
-        # (two launches, same semantics).  The area is kept and only grows; launches sharing it are ordered on the caller's stream.
+        # (two launches, same semantics: ALL reads of the move precede ALL writes, so the area holds the whole move).  The area is bounded:
+        # a move that would need more than _STAGING_MAX_BYTES is refused rather than silently pinning gigabytes.  Eager calls share
+        # one area per stream, grown on demand and released when a much smaller move follows; a call made while the stream is CAPTURING
+        # gets a fresh area from the graph's private pool (nothing allocated under one capture is reused by another: the bmm.py rule).
         need = n * self.sum_row_bytes
-        if self._staging is None or self._staging.numel() < need:
-            self._staging = torch.empty(need, dtype=torch.uint8, device=dev)
+        if need > _STAGING_MAX_BYTES:
+            raise RuntimeError(f"move_kv_cache: {n} rows x {self.sum_row_bytes} B = {need} B of staging exceed the {_STAGING_MAX_BYTES} B bound; "
+                               "split the move into independent (non-overlapping) batches")
+        if torch.cuda.is_current_stream_capturing():
+            staging = torch.empty(need, dtype=torch.uint8, device=dev)
+        else:
+            key = stream_ptr(dev)
+            staging = self._staging.get(key)
+            if staging is None or staging.numel() < need or staging.numel() > 8 * max(need, 1 << 20):
+                staging = self._staging[key] = torch.empty(need, dtype=torch.uint8, device=dev)
         check(lib.fl_kv_move_staged(self.data_ptrs.data_ptr(), self.row_bytes.data_ptr(), self.row_prefix.data_ptr(), len(self.buffers),
-                                    t.data_ptr(), s.data_ptr(), n, self.num_slots, self._staging.data_ptr(), self._staging.numel(),
+                                    t.data_ptr(), s.data_ptr(), n, self.num_slots, staging.data_ptr(), staging.numel(),
                                     self.sum_row_bytes, stream_ptr(dev)), "fl_kv_move_staged")
 
 

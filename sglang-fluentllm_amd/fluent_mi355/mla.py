@@ -192,6 +192,8 @@ def dequantize_ckv_fused_indexed(k_lora_fp8: torch.Tensor, k_rope: torch.Tensor,
     return lora, rope
 
 
+lib.fl_mla_set_merge_timeout.argtypes = [ctypes.c_double]
+lib.fl_mla_set_merge_timeout.restype = ctypes.c_int
 lib.fl_mla_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
 lib.fl_mla_workspace_bytes.restype = ctypes.c_int
@@ -327,3 +329,9 @@ def flash_mla_with_kvcache(q: torch.Tensor, k_cache: torch.Tensor, block_table: 
     out, lse, _ws = _common(a, q, block_table, cache_seqlens, tile_scheduler_metadata, num_splits, softmax_scale, causal)
     _decode(a, q.device)
     return out, lse
+
+
+def set_merge_timeout(seconds: float) -> None:
+    """Budget of the in-kernel split merge's wait for a request's other pieces (default 2 s; env FLUENT_MLA_MERGE_TIMEOUT_S).  A merger that
+    gives up poisons its rows with NaN and the NEXT decode call raises (include/fluent_mi355.h: fl_mla_set_merge_timeout).  Synchronises."""
+    check(lib.fl_mla_set_merge_timeout(float(seconds)), "fl_mla_set_merge_timeout")

@@ -28,9 +28,9 @@ def test_library_exports_all_declared_symbols():
     assert not missing, missing
     lib.fl_version.restype = ctypes.c_int
     m = re.search(r"#define\s+FL_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "fluent_mi355.h")).read())
-    assert lib.fl_version() == int(m.group(1)) == 101          # header, library and the ctypes binding agree
+    assert lib.fl_version() == int(m.group(1)) == 102          # header, library and the ctypes binding agree
     from fluent_mi355 import _lib
-    assert _lib.ABI_VERSION == 101
+    assert _lib.ABI_VERSION == 102
     # an argument struct of another layout is refused, not read past its end
     a = _lib.FlMlaDecodeArgs()
     a.struct_bytes = ctypes.sizeof(_lib.FlMlaDecodeArgs) - 8

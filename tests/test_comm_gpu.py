@@ -75,6 +75,38 @@ def test_fused_add_rmsnorm_pieces(T, H, W):
     assert ulp_close(norm_out, y_ref, frac=2e-2)
 
 
+@pytest.mark.gpu
+def test_flashinfer_norm_entry_points_gemma_offset_and_strided_in_place():
+    """flashinfer.norm: the Gemma forms add the 1 in fp32 (bf16(w + 1) sits on the 2^-7 grid: small gammas would be lost); a strided
+    `out` / in-place pair is written through the CALLER's tensors, never through a reshaped copy of them."""
+    import flashinfer.norm as fn
+    g = torch.Generator().manual_seed(11)
+    T, H = 6, 2048
+    x = torch.randn(T, H, generator=g).to(torch.bfloat16)
+    w = (0.003 * torch.randn(H, generator=g)).to(torch.bfloat16)          # |w| << 2^-7: invisible after bf16(w + 1)
+    xf = x.float()
+    ref = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * (1.0 + w.float())).to(torch.bfloat16)
+    y = fn.gemma_rmsnorm(x.to(dev()), w.to(dev()), 1e-6)
+    assert ulp_close(y, ref, frac=2e-2)
+    assert not torch.equal(ref, (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * (w + 1.0).float()).to(torch.bfloat16))   # the test can tell
+    # in place, both operands strided views of wider tensors ([T, 2, H] -> [:, 0]): 3-D and not viewable as [rows, H]
+    big_x = torch.randn(T, 2, 3, H, generator=g).to(torch.bfloat16).to(dev())
+    big_r = torch.randn(T, 2, 3, H, generator=g).to(torch.bfloat16).to(dev())
+    xin, rin = big_x[:, 0], big_r[:, 1]
+    x0, r0 = xin.clone(), rin.clone()
+    keep_x, keep_r = big_x[:, 1].clone(), big_r[:, 0].clone()
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16)
+    y_ref, r_ref = norm_ref.fused_add_rmsnorm(x0.reshape(1, -1, H).cpu(), None, r0.reshape(-1, H).cpu(), gamma, 1e-6)
+    fn.fused_add_rmsnorm(xin, rin, gamma.to(dev()), 1e-6)
+    torch.cuda.synchronize()
+    assert ulp_close(rin.reshape(-1, H), r_ref, frac=2e-2) and ulp_close(xin.reshape(-1, H), y_ref, frac=2e-2)
+    assert torch.equal(big_x[:, 1], keep_x) and torch.equal(big_r[:, 0], keep_r)      # the neighbours are untouched
+    out = torch.zeros(T, 2, H, dtype=torch.bfloat16, device=dev())
+    fn.rmsnorm(x.to(dev()), gamma.to(dev()), 1e-6, out=out[:, 1])
+    torch.cuda.synchronize()
+    assert ulp_close(out[:, 1], norm_ref.rmsnorm_native(x, gamma, 1e-6), frac=2e-2) and int(out[:, 0].abs().sum()) == 0
+
+
 def test_reducescatter_and_allgather_fusion_world1(comm):
     g = torch.Generator().manual_seed(5)
     _, ws = comm.trtllm_create_ipc_workspace_for_all_reduce_fusion(0, 1, 64, 7168)

@@ -889,3 +889,42 @@ def test_in_kernel_split_merge_is_deterministic_and_makes_progress_beside_a_gemm
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["beside_gemm"] == (beside_gemm == "1") and rec["iterations"] == 120 and rec["split_requests"] > 100
     assert rec["mismatching_launches"] == 0 and rec["merge_counters_back_to_zero"], rec
+
+
+@pytest.mark.gpu
+def test_in_kernel_split_merge_timeout_is_reported_not_silent(fm):
+    """a merger that gives up waiting for a request's other pieces writes NaN into the request's rows AND the next decode call
+    raises.  Forced here by handing the kernel scheduler metadata whose second part does no work (its pieces never arrive)."""
+    from fluent_mi355 import mla as hip_mla
+    H, bs = 128, 64                                   # 64 requests on 128 parts: every request is cut in two and merged inside the kernel
+    c = make_paged_case([4096] * bs, H, 1, seed=3)
+    d = {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in c.items()}
+    pages = c["total_pages"]
+    qn, qs, qr = fm.quantize_ckv_per_token_head(d["q"].contiguous(), 512)
+
+    def decode(meta, ns):
+        return fm.flash_mla_ckv_fp8_per_token(
+            q_nope=qn, q_rope=qr, k_cache_lora=d["k_lora"].view(pages, 64, 1, 512), k_cache_rope=d["k_rope"].view(pages, 64, 1, 64),
+            q_scale=qs, k_scale=d["k_scale"].view(pages, 64, 1, 1), block_table=d["block_table"], cache_seqlens=d["cache_seqlens"],
+            head_dim_v=512, tile_scheduler_metadata=meta, num_splits=ns, softmax_scale=SCALE, causal=True)
+
+    meta, ns = fm.get_mla_metadata(d["cache_seqlens"], H, 1)
+    good, _ = decode(meta, ns)
+    torch.cuda.synchronize()
+    assert int(ns[1]) == 2 and int(meta[1, 0]) == 0      # request 0 = parts 0 and 1
+    bad = meta.clone()
+    bad[1, 0:4] = torch.tensor([bs, 0, bs, 0], dtype=torch.int32)   # part 1 does nothing: request 0's second piece never arrives
+    hip_mla.set_merge_timeout(0.05)
+    try:
+        o, lse = decode(bad, ns)
+        torch.cuda.synchronize()
+        assert torch.isnan(o[0].float()).all() and torch.isnan(lse[0]).all()          # poisoned, not plausible numbers
+        assert torch.equal(o[2:].view(torch.int16), good[2:].view(torch.int16))        # the other requests are untouched
+        with pytest.raises(RuntimeError, match="gave up waiting"):
+            decode(meta, ns)
+    finally:
+        hip_mla.set_merge_timeout(2.0)
+    meta2, ns2 = fm.get_mla_metadata(d["cache_seqlens"], H, 1)                        # rebuilt metadata: business as usual
+    again, _ = decode(meta2, ns2)
+    torch.cuda.synchronize()
+    assert torch.equal(again.view(torch.int16), good.view(torch.int16))
