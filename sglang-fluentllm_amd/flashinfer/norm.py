@@ -59,11 +59,3 @@ def _rmsnorm_fused_parallel(input1, weight1, output1, input2, weight2, output2, 
     rmsnorm(input1, weight1, eps, out=output1)
     rmsnorm(input2, weight2, eps, out=output2)
 
-
-def gemma_rmsnorm(input, weight, eps=1e-6, out=None, enable_pdl=False):
-    """Gemma form (layernorm.py:26-31,209-233): the learned weight is an offset from 1."""
-    return rmsnorm(input, weight + 1.0, eps, out=out)
-
-
-def gemma_fused_add_rmsnorm(input, residual, weight, eps=1e-6, enable_pdl=False):
-    fused_add_rmsnorm(input, residual, weight + 1.0, eps)
