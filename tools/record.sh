@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU box: the round's record — full GPU suite, randomized GEMM parity sweep, PMC passes of the 192 x 256 grouped GEMM, one-batch sweep, kernel trace of
-# the bench, the bench line.  usage: bash tools/r06_record.sh [skip-tests]
+# the bench, the bench line.  usage: bash tools/record.sh [skip-tests]   (output: gpurun_out/record/)
 set -x
-O=gpurun_out/r06_record; mkdir -p $O
+O=gpurun_out/record; mkdir -p $O
 if [ "$1" != "skip-tests" ]; then
   timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
   timeout 900 python tools/stress_gemm.py 24 6 > $O/stress_gemm.txt 2>&1; tail -2 $O/stress_gemm.txt
