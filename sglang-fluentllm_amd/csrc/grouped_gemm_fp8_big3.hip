@@ -38,6 +38,7 @@ __device__ unsigned long long* g_g3dbg = nullptr;
 #define G3T(i) do { } while (0)
 #endif
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM3 = 192;                  // token rows per workgroup
 constexpr int BN3 = 256;                  // weight rows per workgroup
 constexpr int BKH3 = 64;                  // half k block (bytes per row per ring slot)
@@ -671,16 +672,32 @@ __global__ __launch_bounds__(256, 1) void grouped_gemm_fp8_big3_kernel(const Gem
                 make_uint2(fl_pack_bf16(acc[i][j][4 * g + 0] * cm, acc[i][j][4 * g + 1] * cm),
                            fl_pack_bf16(acc[i][j][4 * g + 2] * cm, acc[i][j][4 * g + 3] * cm));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-private buffer: the wave's own writes, in order)
+        // All eight reads of the block go out together and the stores take a 32-bit lane offset against a scalar row base (round 6: hipcc's form of
+        // "read one row, wait, multiply a 64-bit address, store, next row" behind a per-row exec branch was 7,400 cycles per tile — a quarter of a
+        // K = 2048 tile).  Row r = 4 k + rr of the block, 16-byte chunk rc of the staged row = weight columns 8 (rc ^ (r & 15)).
+        u32x4 ev[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int r = 4 * k + rr;
-          const int c = rc ^ (r & 15);
-          const uint4 v = *reinterpret_cast<const uint4*>(stg + r * 256 + (rc << 4));
-          const long long m = cur.row0 + 32 * (2 * j + wm) + r;
-          const int n = cur.n0 + 128 * wn + 8 * c;
-          if (m < cur.row_end) *reinterpret_cast<uint4*>(p.out + m * p.N + n) = v;
+        for (int k = 0; k < 8; ++k) ev[k] = *reinterpret_cast<const u32x4*>(stg + (4 * k + rr) * 256 + (rc << 4));
+        const int blk_row = 32 * (2 * j + wm);
+        const long long rows_left = cur.row_end - cur.row0 - blk_row;                  // rows of the group in this block (wave-uniform)
+        const uint8_t* ob = uniform(reinterpret_cast<const uint8_t*>(p.out + (cur.row0 + blk_row) * p.N + cur.n0 + 128 * wn));
+        const unsigned row_bytes = (unsigned)p.N * 2u;
+        const unsigned lane_off = (unsigned)rr * row_bytes;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (rows_left >= 32) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const unsigned voff = lane_off + (unsigned)((rc ^ ((4 * k + rr) & 15)) << 4);
+            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(ev[k]), "s"(ob + (long long)(4 * k) * row_bytes) : "memory");
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const unsigned voff = lane_off + (unsigned)((rc ^ ((4 * k + rr) & 15)) << 4);
+            if (4 * k + rr < rows_left)
+              asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(ev[k]), "s"(ob + (long long)(4 * k) * row_bytes) : "memory");
+          }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the buffer
       }
     }
 #ifdef FL_GEMM3_TIMING
