@@ -185,6 +185,29 @@ def test_get_mla_metadata_bit_exact(fm, lens, rows):
     assert meta2.shape == meta.shape
 
 
+@pytest.mark.gpu
+def test_get_mla_metadata_bit_exact_on_random_batches(fm):
+    """K3's one-walk kernel against the Python statement on 300 seeded random batches (uniform / ragged / zero-length runs / more requests than parts /
+    one long request), every rows-per-request class of the chip (1, 2, 4, 8 row groups -> 256 .. 32 parts)."""
+    import random
+    rnd = random.Random(20260930)
+    for it in range(300):
+        bs = rnd.choice([1, 2, 3, 5, 8, 16, 33, 64, 128, 200, 256, 700])
+        mx = rnd.choice([1, 63, 64, 65, 500, 4096, 9000, 40000])
+        kind = rnd.random()
+        if kind < 0.25:
+            lens = [mx] * bs
+        elif kind < 0.5:
+            lens = [rnd.choice([0, 1, mx]) for _ in range(bs)]
+        else:
+            lens = [rnd.randint(0, mx) for _ in range(bs)]
+        rows = rnd.choice([16, 64, 128, 256, 512])
+        seq = torch.tensor(lens, dtype=torch.int32, device=dev())
+        meta, ns = fm.get_mla_metadata(seq, rows, 1)
+        rmeta, rns = mla_ref.get_mla_metadata(lens, meta.shape[0])
+        assert np.array_equal(meta.cpu().numpy(), rmeta) and np.array_equal(ns.cpu().numpy(), rns), (it, bs, mx, rows, lens[:8])
+
+
 # ---------------------------------------------------------------- K1: decode parity
 LAST_CASE = {}   # inputs of the most recent run_decode: a failing check() dumps them (a flake must leave evidence)
 
