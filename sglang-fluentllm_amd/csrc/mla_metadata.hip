@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void mla_metadata_fast_kernel(const int32_t* _
     // lane l walks capacity p_min + l.  State: r = first unfinished request, y = end of the open part, w0..w2 = C[r..r+2], ld = C[r + 3] in
     // flight (issued at the end of the previous iteration, consumed at the end of this one: the LDS latency sits beside the iteration's VALU
     // work).  SELECTS ONLY (a divergent branch per event costs more than the whole body: hipcc's exec-mask blocks wait for their LDS read), and
-    // ONE unconditional store per event: the would-be
-    // start of part p + 1 goes to row p + 1 every iteration — the iteration that closes part p writes it last.  A walk that has finished its
+    // ONE unconditional store per event: the would-be start of part p + 1 goes to row p + 1 every iteration — the iteration that closes part
+    // p writes it last.  A walk that has finished its
     // requests keeps closing empty parts at positions >= total (C[bs + 1] = "never reached" stops the advance): a row holds a real part start
     // iff its position is < total, and the capacity fits iff row num_parts does not.  ~18 instructions per event.
     const int P = p_min + lane;
