@@ -447,7 +447,11 @@ def gemm_roofline(dev):
         ws[e].copy_(torch.roll(ws1, r, 0))
     del w1, ws1
     res = {"workload": "w13 grouped GEMM, 256 experts top-8 uniform routing, hidden 7168, 2 x inter 4096, fp8 e4m3 1x128 / 128x128 block scales",
-           "operands": "N(0,1) through the path's quantisers (weights 128x128-block amax/448, activations 1x128)"}
+           "operands": "N(0,1) through the path's quantisers (weights 128x128-block amax/448, activations 1x128)",
+           "kernel": ("grouped_gemm_fp8_big3_kernel (192 x 256 tile, one wave per SIMD; FLUENT_GEMM_BIG=2 selects the 256 x 256 8-wave kernel)"
+                      if os.environ.get("FLUENT_GEMM_BIG", "3")[:1] == "3" else "FLUENT_GEMM_BIG=" + os.environ.get("FLUENT_GEMM_BIG", "")),
+           "binding": "compute regime: the refill's bytes through the CU's vector-memory path + the format's 1 VALU multiply per accumulator register "
+                      "and k block (profiles/r06_gemm_big3_bounding_ladder.txt); decode regime (T128): HBM"}
 
     def timed(T, iters, xq, xs, ex, M, sample=None):
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
@@ -849,10 +853,17 @@ def main():
 
         ms_other = timed_graph(fused_step, max(3, a.steps // 2))
         ms_quant = timed_graph(quant_only_step, max(3, a.steps // 2))
+
+        def k3_only():   # K3 alone, 32 calls per replay (host clock around the replays: the replay overhead is in) (the reference runs it once per step on the host-critical path: flashmla_backend.py:380-387)
+            for _ in range(32):
+                fm.get_mla_metadata(wl["seqlens"], S_Q * H, 1)
+
+        ms_k3 = timed_graph(k3_only, max(3, a.steps // 2)) / 32.0
         other = "K5, K4 separate (reference call sequence)" if FUSED_QUANT else "K5 + K4 fused (flash_mla_fp8.quantize_q_and_cache_k, extension)"
         step_variants = {"other_quant_form": {"quant_launch": other, "ms_per_step": round(ms_other, 4),
                                               "tokens_per_s": round(BS / (ms_other * 1e-3) * (layers / LAYERS), 1)},
                          "quant_launches_only_ms_per_step": round(ms_quant, 4),
+                         "k3_us_per_call": round(ms_k3 * 1e3, 2),
                          "k1_us_per_launch_inside_the_timed_step": round((ms_per_step - ms_quant) * 1e3 / layers, 2)}
 
     # ---- roofline of the dominant kernel: K1 alone, HIP events on the launch stream (torch's current stream) ----

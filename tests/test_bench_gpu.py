@@ -36,6 +36,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys_and_the_config4_child
     assert abs(roof["mfma_frac"] - flops / (roof["us_per_launch"] * 1e-6) / 5e15) < 2e-3
     assert roof["sclk_mhz_mean"] is None or 300 <= roof["sclk_mhz_mean"] <= 3000
     assert roof["power_w_mean"] is None or 50 <= roof["power_w_mean"] <= 2500
+    step = (d.get("variants") or {}).get("step")
+    if step is not None:                                             # (round 6) K3 alone rides in the record: it is on the host-critical path of a replay
+        assert 0 < step["k3_us_per_call"] < 200
     c4 = d["cfg4"]
     assert c4 is not None and "error" not in c4, c4
     assert c4["value"] > 0 and c4["scaling"] == "strong" and c4["config"]["data_connected"] is True and "attempt" in c4
