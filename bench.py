@@ -914,7 +914,7 @@ def main():
         # WRITE_SIZE, MI355X_MICROARCH.md) of the kernel this build dispatches at this workload; the source file is named
         traffic, traffic_src = None, None
         try:
-            traffic_src = "profiles/r05_pmc_traffic.json"
+            traffic_src = "profiles/r06_pmc_traffic.json"
             with open(os.path.join(ROOT, traffic_src)) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch"])
         except Exception:
