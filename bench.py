@@ -500,6 +500,15 @@ def gemm_roofline(dev):
         if smp is not None:
             res[f"T{T}"].update({"sclk_mhz_mean": smp.get("sclk_mhz_mean"), "power_w_mean": smp.get("power_w_mean"),
                                  "power_cap_w": smp.get("power_cap_w"), "sampler": smp})
+        if T == 16384:
+            # what `binding` means in numbers: the bytes the 192 x 256 kernel pulls through each CU's vector-memory path (every tile refills
+            # (192 + 256) rows x 128 B per k block, whatever L2 / HBM serves them) against what that path was measured to sustain per CU
+            # (profiles/r06_gemm_big3_bounding_ladder.txt (4), r02_probe_dma_rate.txt: ~42-45 GB/s from HBM, ~120 from L2)
+            tiles = int(((counts + 191) // 192).sum()) * (N // 256)
+            refill = tiles * (HID // 128) * (192 + 256) * 128
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            res[f"T{T}"].update({"refill_bytes_per_launch": refill, "refill_GBs_per_cu": round(refill / t / 1e9 / cus, 1),
+                                 "refill_GBs_per_cu_measured_ceilings": {"hbm_sourced": 45, "l2_resident": 120}})
         if T == 16384:   # the same launch on uniformly random bytes (maximal operand toggling; round 1's operands)
             flat = w.view(-1).view(torch.uint8)
             step = 1 << 28
