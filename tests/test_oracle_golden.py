@@ -238,3 +238,33 @@ def test_metadata_positions_statement_equals_the_two_walk_statement():
     for lens, parts in cases:
         a, b = mla_ref.get_mla_metadata(lens, parts), mla_ref.get_mla_metadata_positions(lens, parts)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (lens[:8], len(lens), parts)
+
+
+def test_metadata_statements_agree_property_based():
+    """hypothesis: arbitrary small batches (zero-length requests included) and part counts — the cost-axis statement equals the two-walk statement, every
+    request is covered exactly once, parts are contiguous and num_splits counts the parts that touch a request."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.lists(st.integers(min_value=0, max_value=3000), min_size=0, max_size=40), st.sampled_from([1, 2, 3, 5, 8, 16, 32, 64, 128, 256]))
+    def check(lens, parts):
+        a, b = mla_ref.get_mla_metadata(lens, parts), mla_ref.get_mla_metadata_positions(lens, parts)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        meta, ns = a
+        bs = len(lens)
+        nt = [(L + 63) // 64 if L > 0 else 0 for L in lens]
+        touched = [0] * bs
+        prev_end = (0, 0)
+        for p in range(parts):
+            br, bt, er, et = (int(x) for x in meta[p, :4])
+            if br >= bs:
+                assert (er, et) == (bs, 0)
+                continue
+            assert (br, bt) == prev_end and (er, et) >= (br, bt)            # contiguous, monotone
+            for r in range(br, min(er + (1 if et > 0 else 0), bs)):
+                touched[r] += 1
+            assert et == 0 or et < nt[er]
+            prev_end = (er, et)
+        assert prev_end == (bs, 0) or bs == 0
+        assert [int(ns[r + 1] - ns[r]) for r in range(bs)] == touched
+    check()
