@@ -284,6 +284,14 @@ def test_public_fusion_entry_points_take_the_oneshot_route_when_enabled(monkeypa
             how = "" if ref is None else (f"; vs CPU: default route {int((a.cpu().view(torch.int16).int() - ref.view(torch.int16).int()).abs().max())} ulp max, "
                                           f"one-shot route {int((b.cpu().view(torch.int16).int() - ref.view(torch.int16).int()).abs().max())} ulp max")
             idx = (d > 0).nonzero()
+            try:   # evidence for the offline post-mortem: both routes' tensor -> gpurun_out/failures/ (merged back from the GPU box)
+                import numpy as np
+                root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "failures")
+                os.makedirs(root, exist_ok=True)
+                np.savez_compressed(os.path.join(root, f"two_route_{name}.npz"), default=a.cpu().view(torch.int16).numpy(),
+                                    oneshot=b.cpu().view(torch.int16).numpy() if b.dtype == torch.bfloat16 else b.cpu().numpy())
+            except Exception:
+                pass
             raise AssertionError(f"{name}: {idx.shape[0]} elements differ between the routes (first {idx[:4].tolist()}, max |diff| {float(d.max()):.4g}){how}")
 
 
