@@ -588,9 +588,19 @@ extern "C" int fl_comm_check(void* comm) {   // synchronises the device: not for
   return FL_OK;
 }
 
+namespace {
+// Every XCD writes its L2 back (a system-scope release fence per workgroup; far more workgroups than XCDs).  fl_comm_destroy runs it in front of
+// hipFree of the UNCACHED workspace: round 6's suite soak saw a contiguous, line-aligned range of ANOTHER tensor written by the communicator's
+// last kernel read back stale right after the workspace was freed (5 of ~26 full-suite runs, never with the communicator alive) — dirty lines
+// must not depend on what the driver does to the caches when it unmaps uncached memory.
+__global__ void l2_writeback_kernel() { __threadfence_system(); }
+}  // namespace
+
 extern "C" int fl_comm_destroy(void* comm) {
   FlComm* c = (FlComm*)comm;
   if (!c) return FL_OK;
+  (void)hipDeviceSynchronize();
+  l2_writeback_kernel<<<256, 64>>>();
   (void)hipDeviceSynchronize();
   for (int p = 0; p < c->world; ++p)
     if (c->opened[p]) (void)hipIpcCloseMemHandle(c->peer[p]);

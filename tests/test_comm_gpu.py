@@ -274,7 +274,10 @@ def test_public_fusion_entry_points_take_the_oneshot_route_when_enabled(monkeypa
                                          num_token_current_rank=T, pattern_code=comm.ReduceScatterFusionPattern.kRSResidualRMSNorm,
                                          residual_in=res, residual_out=r2, norm_out=n2, rms_gamma=gamma, rms_eps=1e-6)
         torch.cuda.synchronize()
-        got.append([r, n, q.view(torch.uint8), sc, r2, n2])
+        # (outputs are taken off the device while the communicator is alive, as a server consumes them: see fl_comm_destroy on what was seen
+        #  when the uncached workspace was freed first)
+        got.append([t_.clone() for t_ in (r, n, q.view(torch.uint8), sc, r2, n2)])
+        torch.cuda.synchronize()
         comm.trtllm_destroy_ipc_workspace_for_all_reduce_fusion(handles)
     y_ref, r_ref = norm_ref.fused_add_rmsnorm(x.cpu().reshape(1, T, H), None, res.cpu(), gamma.cpu(), 1e-6)
     for name, a, b in zip(("residual_out", "norm_out", "quant_out", "scale_out", "rs_residual_out", "rs_norm_out"), *got):
