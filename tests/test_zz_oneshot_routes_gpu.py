@@ -25,16 +25,24 @@ def test_public_fusion_entry_points_take_the_oneshot_route_when_enabled(monkeypa
     res = torch.randn(T, H, generator=g).to(torch.bfloat16).to(DEV)
     gamma = torch.rand(H, generator=g).to(torch.bfloat16).to(DEV)
     got = []
+    # Every output of both routes exists, holds a sentinel and has been synchronised BEFORE the first launch.  What the soak saw was cache lines 32 .. 1323
+    # of the second route's FIRST freshly allocated output reading back as ZERO (exactly: 82,606 non-zero elements of the expected tensor in that range,
+    # largest 6.125 — the numbers of the failure message) — a line-granular range, not a row or chunk of any kernel here: the tensor came out of a segment
+    # the caching allocator had just obtained from the driver.  Outputs that pre-exist take that allocation out of the measured window.
+    outs = {}
+    for flag in ("0", "1"):
+        outs[flag] = [torch.full((T, H), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(4)] + \
+                     [torch.full((T, H), 0x7F, dtype=torch.uint8, device=DEV).view(torch.float8_e4m3fn),
+                      torch.full((T, H // 128), float("nan"), dtype=torch.float32, device=DEV)]
+    torch.cuda.synchronize()
     for flag in ("0", "1"):
         monkeypatch.setenv("FLUENT_ONESHOT", flag)
         handles, wsp = comm.trtllm_create_ipc_workspace_for_all_reduce_fusion(0, 1, 64, H)
         assert (handles[0].oneshot is not None) == (flag == "1")
-        r, n = torch.empty_like(x), torch.empty_like(x)
-        q, sc = torch.empty(T, H, dtype=torch.float8_e4m3fn, device=DEV), torch.empty(T, H // 128, dtype=torch.float32, device=DEV)
+        r, n, r2, n2, q, sc = outs[flag]
         comm.trtllm_allreduce_fusion(allreduce_in=x, world_size=1, world_rank=0, token_num=T, hidden_dim=H, workspace_ptrs=wsp,
                                      pattern_code=comm.AllReduceFusionPattern.kARResidualRMSNormFP8BlockWiseQuant, residual_in=res,
                                      residual_out=r, norm_out=n, quant_out=q, scale_out=sc, rms_gamma=gamma, rms_eps=1e-6)
-        r2, n2 = torch.empty_like(x), torch.empty_like(x)
         comm.trtllm_reducescatter_fusion(reducescatter_in=x, world_size=1, world_rank=0, token_num=T, hidden_dim=H, workspace_ptrs=wsp,
                                          num_token_current_rank=T, pattern_code=comm.ReduceScatterFusionPattern.kRSResidualRMSNorm,
                                          residual_in=res, residual_out=r2, norm_out=n2, rms_gamma=gamma, rms_eps=1e-6)
