@@ -22,10 +22,9 @@ def golden_dir():
 
 @pytest.fixture(autouse=True)
 def _gpu_tests_do_not_overlap(request):
-    """A GPU test starts on an idle device and leaves one: device work a test left in flight on a side stream (a graph replay, a second-stream
-    launch) may still be writing into blocks the caching allocator has already handed to the NEXT test — round 6 saw `residual_out` of
-    test_public_fusion_entry_points_take_the_oneshot_route_when_enabled differ between its two routes in 2 of ~20 full-suite runs and in none of
-    1,200 repetitions of the test alone.  (No effect on CPU tests: torch.cuda is not touched without the `gpu` marker.)"""
+    """A GPU test starts on an idle device and leaves one: device work left in flight on a side stream (a graph replay, a second-stream launch) must
+    not be writing into blocks the caching allocator hands to the NEXT test.  (Hygiene: it did not cure round 6's soak failure — DESIGN.md section 7
+    item 5 — whose cause lay elsewhere.  No effect on CPU tests: torch.cuda is not touched without the `gpu` marker.)"""
     is_gpu = request.node.get_closest_marker("gpu") is not None
     if is_gpu:
         import torch
